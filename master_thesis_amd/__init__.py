@@ -1,0 +1,51 @@
+"""master_thesis_amd - MI355X (gfx950) implementation of the frame-alignment / temporal-copying hot path of
+AlomdaElmasry/master_thesis: all-pairs feature correlation, flow / affine grid warp and masked cross-frame
+context matching, as hand-written HIP kernels behind a C ABI (include/tcl.h, csrc/libtcl_hip.so).
+
+The sub-modules mirror the reference's module and function names for this path:
+
+    master_thesis_amd.utils.correlation   <- utils/correlation.py
+    master_thesis_amd.utils.flow          <- utils/flow.py
+    master_thesis_amd.models.cpn          <- the hot-path parts of models/cpn.py
+    master_thesis_amd.models.cpn_original <- CM_Module of models/cpn_original.py
+
+`install_dropin()` registers them under the reference's own names (`utils.correlation`, `utils.flow`, and the
+hot-path symbols of `models.cpn` / `models.cpn_original`), see INTEGRATION.md.
+"""
+from . import _lib  # noqa: F401
+from ._lib import LIB_PATH, TclError, lib  # noqa: F401
+
+__version__ = "0.1.0"
+
+
+def install_dropin(reference_modules=None):
+    """Patch the reference's hot-path symbols in place with this package's implementations.
+
+    reference_modules: optional dict with already-imported reference modules
+        {'utils.correlation': mod, 'utils.flow': mod, 'models.cpn': mod, 'models.cpn_original': mod};
+    by default they are looked up in sys.modules.  Only functions/classes on the hot path are replaced; the conv
+    stacks, runners and data code of the reference stay untouched.
+    """
+    import sys
+
+    from .models import cpn as _cpn
+    from .models import cpn_original as _cpo
+    from .utils import correlation as _corr
+    from .utils import flow as _flow
+
+    mods = reference_modules or sys.modules
+    table = {
+        "utils.correlation": (_corr, ["compute_masked_correlation", "compute_masked_4d_correlation"]),
+        "utils.flow": (_flow, ["corr_to_flow", "flow_abs_to_relative", "flow_relative_to_abs", "crop_flow", "resize_flow", "align_set"]),
+        "models.cpn": (_cpn, ["masked_softmax", "add_match_border", "add_border", "CPNContextMatchingDefault", "CPNContextMatchingComplete"]),
+        "models.cpn_original": (_cpo, ["CM_Module"]),
+    }
+    patched = []
+    for name, (src, symbols) in table.items():
+        target = mods.get(name)
+        if target is None:
+            continue
+        for sym in symbols:
+            setattr(target, sym, getattr(src, sym))
+            patched.append("%s.%s" % (name, sym))
+    return patched

@@ -1,0 +1,83 @@
+// Shared helpers for the libtcl_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/tcl.h"
+
+namespace tcl {
+
+int set_error(int code, const char *fmt, ...);  // records the thread-local message, returns code
+int check_launch(const char *what);             // hipGetLastError -> TCL_ERR_LAUNCH
+
+inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// hardware facts used for launch sizing (MI355X: 8 XCDs x 32 CUs)
+constexpr int kNumXCD = 8;
+constexpr int kNumCU = 256;
+constexpr int kMaxStreamBlocks = kNumCU * 8;  // grid cap for grid-stride bandwidth kernels
+
+constexpr float kNormEps = 1e-9f;
+
+#define TCL_REQUIRE(cond, code, ...)                         \
+  do {                                                       \
+    if (!(cond)) return ::tcl::set_error((code), __VA_ARGS__); \
+  } while (0)
+
+// wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: blocks are dealt round-robin over the 8 XCDs, so give each
+// XCD a contiguous chunk of the logical tile order (neighbouring tiles then share one L2).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk / kNumXCD, r = nblk % kNumXCD;
+  const unsigned xcd = bid % kNumXCD, idx = bid / kNumXCD;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+
+// torch.linspace(-1, 1, n)[i] in fp32 (evaluated symmetrically from both ends), optionally scaled by (n-1)/n:
+// the base coordinate of F.affine_grid for align_corners = True / False.
+__device__ __forceinline__ float base_coord(int i, int n, bool align_corners) {
+  if (n <= 1) return 0.f;
+  const float step = __fdiv_rn(2.f, (float)(n - 1));
+  float r = (i < n / 2) ? __fadd_rn(-1.f, __fmul_rn(step, (float)i)) : __fsub_rn(1.f, __fmul_rn(step, (float)(n - 1 - i)));
+  if (!align_corners) r = __fdiv_rn(__fmul_rn(r, (float)(n - 1)), (float)n);
+  return r;
+}
+
+// Source taps of F.interpolate(mode='bilinear', align_corners=False): src = scale*(dst+0.5)-0.5 clamped at 0.
+struct LinTap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ LinTap linear_tap(int dst, int in_size, float scale) {
+  float src = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)dst, 0.5f)), 0.5f);
+  if (src < 0.f) src = 0.f;
+  LinTap t;
+  t.i0 = (int)src;
+  if (t.i0 > in_size - 1) t.i0 = in_size - 1;
+  t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+  t.l1 = __fsub_rn(src, (float)t.i0);
+  t.l0 = __fsub_rn(1.f, t.l1);
+  return t;
+}
+// value = (p00*lx0 + p01*lx1)*ly0 + (p10*lx0 + p11*lx1)*ly1, each operation rounded separately
+__device__ __forceinline__ float bilerp(float p00, float p01, float p10, float p11, const LinTap &tx, const LinTap &ty) {
+  const float top = __fadd_rn(__fmul_rn(p00, tx.l0), __fmul_rn(p01, tx.l1));
+  const float bot = __fadd_rn(__fmul_rn(p10, tx.l0), __fmul_rn(p11, tx.l1));
+  return __fadd_rn(__fmul_rn(top, ty.l0), __fmul_rn(bot, ty.l1));
+}
+
+}  // namespace tcl

@@ -1,0 +1,580 @@
+// All-pairs masked feature correlation (cost volume), forward and backward, plus the per-pixel
+// correlation and the argmax -> flow reduction, for gfx950.
+//
+// Replaces compute_masked_4d_correlation (utils/correlation.py:28-54), compute_masked_correlation
+// (utils/correlation.py:4-25) and corr_to_flow (utils/flow.py:8-26); see include/tcl.h.
+//
+// Structure of A1 (per batch item b and reference frame f, P = H*W pixels, C channels):
+//   1. normalise:  a^[c][p] = x v / (||x v||_2 + 1e-9)   (one streaming pass; writes the GEMM operands
+//                  k-major, i.e. in the NCHW order they arrive in, and the norms for the backward pass)
+//   2. contraction out[p][q] = sum_c a^[c][p] r^[c][q]    LDS-tiled MFMA GEMM, K = C
+//   backward:      d_a^[c][p] = sum_{f,q} r^[c][q] G[p][q],  d_r^[c][q] = sum_p a^[c][p] G[p][q]
+//                  (two more MFMA GEMMs with K = P), then the normalisation's Jacobian per pixel.
+//
+// TCL_PREC_F32 uses v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD).  The four k-slices of
+// an 8-deep k group are issued as four MFMAs whose lane halves take k = k0+e and k0+4+e (e = 0..3): the
+// same permutation on both operands, so a k-contiguous operand is fetched from LDS with one ds_read_b128
+// per lane (rows padded to 36 floats: conflict-free) and an m-contiguous one with plain ds_read_b32.
+#include "tcl_common.h"
+
+namespace tcl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------ normalise
+// x element (b,c,f,p) at ((b*C + c)*F + f)*P + p; v element (b,f,p); hat element ((b*F+f)*C + c)*P + p.
+// block = 64 pixels x 4 channel groups.
+__global__ void __launch_bounds__(256) corr_normalise_kernel(const float *__restrict__ x, const float *__restrict__ v,
+                                                             float *__restrict__ hat, float *__restrict__ nrm, int C, int F, int P) {
+  const int bf = blockIdx.y, b = bf / F, f = bf - b * F;
+  const int p = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int cg = threadIdx.x >> 6;
+  const bool ok = p < P;
+  const float m = (ok && v) ? v[(int64_t)bf * P + p] : 1.f;
+  const float *xp = x + ((int64_t)b * C * F + f) * P + p;
+  float ss = 0.f;
+  if (ok)
+    for (int c = cg; c < C; c += 4) {
+      const float t = xp[(int64_t)c * F * P] * m;
+      ss += t * t;
+    }
+  __shared__ float red[4][64];
+  red[cg][threadIdx.x & 63] = ss;
+  __syncthreads();
+  if (!ok) return;
+  const int l = threadIdx.x & 63;
+  const float n = sqrtf((red[0][l] + red[1][l]) + (red[2][l] + red[3][l]));
+  const float den = n + kNormEps;
+  float *hp = hat + (int64_t)bf * C * P + p;
+  for (int c = cg; c < C; c += 4) hp[(int64_t)c * P] = (xp[(int64_t)c * F * P] * m) / den;
+  if (cg == 0) nrm[(int64_t)bf * P + p] = n;
+}
+
+// Jacobian of the normalisation: g_x = v * (d_hat/(n+eps) - t * <d_hat,t> / ((n+eps)^2 n)),  0-norm -> first term only.
+__global__ void __launch_bounds__(256) corr_normalise_bwd_kernel(const float *__restrict__ x, const float *__restrict__ v,
+                                                                 const float *__restrict__ dhat, const float *__restrict__ nrm,
+                                                                 float *__restrict__ gx, int C, int F, int P) {
+  const int bf = blockIdx.y, b = bf / F, f = bf - b * F;
+  const int p = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int cg = threadIdx.x >> 6;
+  const bool ok = p < P;
+  const float m = (ok && v) ? v[(int64_t)bf * P + p] : 1.f;
+  const float *xp = x + ((int64_t)b * C * F + f) * P + p;
+  const float *dp = dhat + (int64_t)bf * C * P + p;
+  float dot = 0.f;
+  if (ok)
+    for (int c = cg; c < C; c += 4) dot += dp[(int64_t)c * P] * (xp[(int64_t)c * F * P] * m);
+  __shared__ float red[4][64];
+  red[cg][threadIdx.x & 63] = dot;
+  __syncthreads();
+  if (!ok) return;
+  const int l = threadIdx.x & 63;
+  dot = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  const float n = nrm[(int64_t)bf * P + p];
+  const float ne = n + kNormEps;
+  const float k = n > 0.f ? dot / (ne * ne * n) : 0.f;
+  float *gp = gx + ((int64_t)b * C * F + f) * P + p;
+  for (int c = cg; c < C; c += 4) {
+    const float t = xp[(int64_t)c * F * P] * m;
+    gp[(int64_t)c * F * P] = (dp[(int64_t)c * P] / ne - t * k) * m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ fp32 MFMA GEMM
+struct GemmArgs {
+  const float *A, *B;
+  float *D;
+  int M, N, K;            // K = depth of ONE segment
+  int nseg;               // segments accumulated into the same D (the reference frames, for d_a^)
+  int64_t a_ld, b_ld;     // stride between rows of the contiguous axis
+  int64_t a_bs, b_bs, d_bs;  // batch strides
+  int64_t a_ss, b_ss;     // segment strides
+  int64_t d_ld;
+  int a_bdiv;             // A batch index = z / a_bdiv
+  int nbatch;
+  int tiles_m, tiles_n;
+};
+
+constexpr int BK = 32;
+constexpr int KC_LD = BK + 4;  // padded row of a k-contiguous LDS tile (floats): ds_read_b128 conflict-free
+
+// Stages one operand tile (ROWS x BK, rows = m or n) from global memory into registers.
+//  KC:  element (row,k) at base + row*ld + k   -> LDS [ROWS][KC_LD]
+//  !KC: element (row,k) at base + k*ld + row   -> LDS [BK][ROWS]
+template <int ROWS, int NT, bool KC, bool VEC>
+struct TileLoader {
+  static constexpr int NV = ROWS * BK / 4 / NT;  // float4 per thread
+  static_assert(ROWS * BK / 4 % NT == 0, "tile must divide over the block");
+  f32x4 r[NV];
+
+  __device__ __forceinline__ void load(const float *base, int64_t ld, int row0, int k0, int rows, int depth, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      int row, k;
+      if (KC) { row = idx / (BK / 4); k = (idx % (BK / 4)) * 4; }
+      else    { k = idx / (ROWS / 4); row = (idx % (ROWS / 4)) * 4; }
+      const int gr = row0 + row, gk = k0 + k;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (KC) {
+        if (gr < rows) {
+          const float *p = base + (int64_t)gr * ld + gk;
+          if (VEC) { if (gk < depth) val = *reinterpret_cast<const f32x4 *>(p); }
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (gk + e < depth) val[e] = p[e];
+          }
+        }
+      } else {
+        if (gk < depth) {
+          const float *p = base + (int64_t)gk * ld + gr;
+          if (VEC) { if (gr < rows) val = *reinterpret_cast<const f32x4 *>(p); }
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (gr + e < rows) val[e] = p[e];
+          }
+        }
+      }
+      r[i] = val;
+    }
+  }
+
+  __device__ __forceinline__ void store(float *lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      if (KC) {
+        const int row = idx / (BK / 4), k = (idx % (BK / 4)) * 4;
+        *reinterpret_cast<f32x4 *>(lds + row * KC_LD + k) = r[i];
+      } else {
+        const int k = idx / (ROWS / 4), row = (idx % (ROWS / 4)) * 4;
+        *reinterpret_cast<f32x4 *>(lds + k * ROWS + row) = r[i];
+      }
+    }
+  }
+};
+
+template <int ROWS, bool KC>
+__device__ __forceinline__ f32x4 read_frag(const float *lds, int row, int kbase) {
+  // -> the four k-slices (kbase + e, e = 0..3) of one row, for this lane
+  if (KC) return *reinterpret_cast<const f32x4 *>(lds + row * KC_LD + kbase);
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = lds[(kbase + e) * ROWS + row];
+  return v;
+}
+
+// D[m][n] (+)= sum_k A(m,k) B(n,k); block tile BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN).
+// EPI_STORE writes D; EPI_ARGMAX instead reduces every row of the tile to (max value, first column reaching it) and
+// writes that pair to g.D as float2 at [z][m][n-tile] (the volume itself never reaches HBM).
+enum { EPI_STORE = 0, EPI_ARGMAX = 1 };
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int EPI>
+__global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_LDS = A_KC ? BM * KC_LD : BK * BM;
+  constexpr int B_LDS = B_KC ? BN * KC_LD : BK * BN;
+  __shared__ __attribute__((aligned(16))) float smem[A_LDS + B_LDS];
+  float *As = smem, *Bs = smem + A_LDS;
+
+  // block -> (batch, m-tile, n-tile): XCD-contiguous chunks, grouped so that neighbours share operand panels
+  const unsigned per_batch = g.tiles_m * g.tiles_n;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned z = lin / per_batch, local = lin - z * per_batch;
+  constexpr unsigned GROUP = 8;
+  const unsigned gw = GROUP * g.tiles_n;
+  const unsigned gid = local / gw, first_m = gid * GROUP;
+  const unsigned gsz = min((unsigned)g.tiles_m - first_m, GROUP);
+  const unsigned tm = first_m + (local % gw) % gsz, tn = (local % gw) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const float *Ab = g.A + (int64_t)(z / g.a_bdiv) * g.a_bs;
+  const float *Bb = g.B + (int64_t)z * g.b_bs;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TileLoader<BM, NT, A_KC, VEC> la;
+  TileLoader<BN, NT, B_KC, VEC> lb;
+  const int ktiles = (g.K + BK - 1) / BK;
+  const int total = ktiles * g.nseg;
+
+  la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
+  lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
+  for (int t = 0; t < total; ++t) {
+    la.store(As, tid);
+    lb.store(Bs, tid);
+    __syncthreads();
+    if (t + 1 < total) {  // prefetch the next tile while this one is multiplied
+      const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
+      la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BK, g.M, g.K, tid);
+      lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BK, g.N, g.K, tid);
+    }
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_KC>(As, wm0 + i * 32 + lr, kg * 8 + lh * 4);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_KC>(Bs, wn0 + j * 32 + lr, kg * 8 + lh * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  if (EPI == EPI_ARGMAX) {
+    // smem is free again (the loop ended on a barrier): [BM][WN] (value, column) pairs
+    float2 *best = reinterpret_cast<float2 *>(smem);
+    static_assert(BM * WN * 2 <= A_LDS + B_LDS, "argmax scratch must fit the staging buffer");
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn0 + j * 32 + lr;
+          const float v = acc[i][j][r];
+          if (n < g.N && (v > bv || bi == 0x7fffffff)) { bv = v; bi = n; }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {  // across the 32 lanes of this half (same row)
+          const float ov = __shfl_xor(bv, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lr == 0) {
+          const int ml = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          best[ml * WN + (wid % WN)] = make_float2(bv, __int_as_float(bi));
+        }
+      }
+    __syncthreads();
+    for (int ml = tid; ml < BM; ml += NT) {
+      const int m = m0 + ml;
+      if (m >= g.M) continue;
+      float2 b = best[ml * WN];
+#pragma unroll
+      for (int k = 1; k < WN; ++k) {
+        const float2 o = best[ml * WN + k];
+        if (o.x > b.x || (o.x == b.x && __float_as_int(o.y) < __float_as_int(b.y))) b = o;
+      }
+      reinterpret_cast<float2 *>(g.D)[((int64_t)z * g.M + m) * g.tiles_n + tn] = b;
+    }
+    return;
+  }
+  float *Db = g.D + (int64_t)z * g.d_bs;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + j * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < g.M && n < g.N) Db[(int64_t)m * g.d_ld + n] = acc[i][j][r];
+      }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI = EPI_STORE>
+static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
+  g.tiles_m = (int)cdiv(g.M, BM);
+  g.tiles_n = (int)cdiv(g.N, BN);
+  const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
+  TCL_REQUIRE(blocks > 0 && blocks < (1LL << 31), TCL_ERR_SHAPE, "%s: grid of %ld blocks", what, (long)blocks);
+  // float4 staging needs 16-byte aligned rows along each operand's contiguous axis
+  const bool vec = aligned(g.A, 16) && aligned(g.B, 16) && g.a_ld % 4 == 0 && g.b_ld % 4 == 0 && g.a_bs % 4 == 0 &&
+                   g.b_bs % 4 == 0 && g.a_ss % 4 == 0 && g.b_ss % 4 == 0 && (A_KC ? g.K % 4 == 0 : g.M % 4 == 0) &&
+                   (B_KC ? g.K % 4 == 0 : g.N % 4 == 0);
+  if (vec)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, true, EPI>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, false, EPI>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
+  return check_launch(what);
+}
+
+// ------------------------------------------------------------------------------------------ workspace layout
+struct CorrWs {
+  float *a_hat, *r_hat, *n_t, *n_r;
+  size_t bytes;
+};
+static CorrWs corr_ws(void *base, int64_t B, int64_t C, int64_t F, int64_t P) {
+  CorrWs w;
+  size_t off = 0;
+  auto take = [&](size_t n) { float *p = (float *)((char *)base + off); off += round_up(n * sizeof(float), 256); return p; };
+  w.a_hat = take((size_t)B * C * P);
+  w.r_hat = take((size_t)B * F * C * P);
+  w.n_t = take((size_t)B * P);
+  w.n_r = take((size_t)B * F * P);
+  w.bytes = off;
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------ A2 per-pixel correlation
+__global__ void __launch_bounds__(256) corr1x1_fwd_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
+                                                          const float *__restrict__ m1, const float *__restrict__ m2,
+                                                          float *__restrict__ out, int C, int P, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / P, p = i - b * P;
+    const float a = m1[i], c2 = m2[i];
+    const float *p1 = f1 + b * C * P + p, *p2 = f2 + b * C * P + p;
+    float s1 = 0.f, s2 = 0.f, d = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float t1 = p1[(int64_t)c * P] * a, t2 = p2[(int64_t)c * P] * c2;
+      s1 += t1 * t1; s2 += t2 * t2; d += t1 * t2;
+    }
+    out[i] = d / ((sqrtf(s1) + kNormEps) * (sqrtf(s2) + kNormEps));
+  }
+}
+
+__global__ void __launch_bounds__(256) corr1x1_bwd_kernel(const float *__restrict__ go, const float *__restrict__ f1,
+                                                          const float *__restrict__ f2, const float *__restrict__ m1,
+                                                          const float *__restrict__ m2, float *__restrict__ g1,
+                                                          float *__restrict__ g2, int C, int P, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / P, p = i - b * P;
+    const float a = m1[i], c2 = m2[i], g = go[i];
+    const float *p1 = f1 + b * C * P + p, *p2 = f2 + b * C * P + p;
+    float s1 = 0.f, s2 = 0.f, d = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float t1 = p1[(int64_t)c * P] * a, t2 = p2[(int64_t)c * P] * c2;
+      s1 += t1 * t1; s2 += t2 * t2; d += t1 * t2;
+    }
+    const float n1 = sqrtf(s1), n2 = sqrtf(s2), e1 = n1 + kNormEps, e2 = n2 + kNormEps;
+    // d_a1^ = g a2^ ; <d_a1^, t1> = g d / e2  (and symmetrically)
+    const float k1 = n1 > 0.f ? (g * d / e2) / (e1 * e1 * n1) : 0.f;
+    const float k2 = n2 > 0.f ? (g * d / e1) / (e2 * e2 * n2) : 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float t1 = p1[(int64_t)c * P] * a, t2 = p2[(int64_t)c * P] * c2;
+      if (g1) g1[b * C * P + (int64_t)c * P + p] = (g * (t2 / e2) / e1 - t1 * k1) * a;
+      if (g2) g2[b * C * P + (int64_t)c * P + p] = (g * (t1 / e1) / e2 - t2 * k2) * c2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ A10 argmax -> flow
+// one wave per target pixel row of S*S similarities; first maximal index wins (torch.argmax on CPU).
+__global__ void __launch_bounds__(256) corr_to_flow_kernel(const float *__restrict__ corr, float *__restrict__ flow,
+                                                           int64_t rows, int S, float scale) {
+  const int Q = S * S;
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    const float *r = corr + row * Q;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int q = lane; q < Q; q += 64) {
+      const float v = r[q];
+      if (v > best || bi == 0x7fffffff) { best = v; bi = q; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+      const int x = bi % S, y = bi / S;
+      reinterpret_cast<float2 *>(flow)[row] =
+          make_float2(__fsub_rn(__fmul_rn((float)x, scale), 1.f), __fsub_rn(__fmul_rn((float)y, scale), 1.f));
+    }
+  }
+}
+
+// rows x ntile (value, column) pairs -> flow; tiles are in column order, so a strict > keeps the first maximum.
+__global__ void __launch_bounds__(256) argmax_tiles_to_flow_kernel(const float2 *__restrict__ part, float *__restrict__ flow, int64_t rows,
+                                                                  int ntile, int S, float scale) {
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (int64_t)gridDim.x * blockDim.x) {
+    float2 b = part[row * ntile];
+    for (int k = 1; k < ntile; ++k) {
+      const float2 o = part[row * ntile + k];
+      if (o.x > b.x) b = o;
+    }
+    const int bi = __float_as_int(b.y), x = bi % S, y = bi / S;
+    reinterpret_cast<float2 *>(flow)[row] = make_float2(__fsub_rn(__fmul_rn((float)x, scale), 1.f), __fsub_rn(__fmul_rn((float)y, scale), 1.f));
+  }
+}
+
+}  // namespace tcl
+
+using namespace tcl;
+
+// ============================================================================================ C ABI
+extern "C" size_t tcl_corr4d_fwd_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P, int precision) {
+  (void)precision;
+  if (B <= 0 || C <= 0 || F <= 0 || P <= 0) return 0;
+  return corr_ws(nullptr, B, C, F, P).bytes;
+}
+
+static int corr_check(const char *fn, int64_t B, int64_t C, int64_t F, int64_t P, int precision) {
+  TCL_REQUIRE(B > 0 && C > 0 && F > 0 && P > 0, TCL_ERR_SHAPE, "%s: bad shape B=%ld C=%ld F=%ld P=%ld", fn, (long)B, (long)C, (long)F, (long)P);
+  TCL_REQUIRE(B * F < 65536 && P < (1 << 24) && C < (1 << 20), TCL_ERR_SHAPE, "%s: shape out of range", fn);
+  TCL_REQUIRE(precision == TCL_PREC_F32, TCL_ERR_UNSUPPORTED, "%s: precision %d is not built in this version", fn, precision);
+  return TCL_OK;
+}
+
+extern "C" int tcl_corr4d_fwd(const float *x_t, const float *v_t, const float *x_r, const float *v_r, float *out, int64_t B,
+                              int64_t C, int64_t F, int64_t P, int precision, void *workspace, size_t workspace_bytes,
+                              void *stream) {
+  int rc = corr_check("tcl_corr4d_fwd", B, C, F, P, precision);
+  if (rc) return rc;
+  TCL_REQUIRE(x_t && x_r && out, TCL_ERR_ARG, "tcl_corr4d_fwd: NULL pointer");
+  const size_t need = tcl_corr4d_fwd_workspace_bytes(B, C, F, P, precision);
+  TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
+              "tcl_corr4d_fwd: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  const CorrWs w = corr_ws(workspace, B, C, F, P);
+  const dim3 blk(256);
+  hipLaunchKernelGGL(corr_normalise_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)B), blk, 0, s, x_t, v_t, w.a_hat, w.n_t, (int)C, 1, (int)P);
+  hipLaunchKernelGGL(corr_normalise_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)(B * F)), blk, 0, s, x_r, v_r, w.r_hat, w.n_r, (int)C, (int)F, (int)P);
+  rc = check_launch("tcl_corr4d_fwd(normalise)");
+  if (rc) return rc;
+  GemmArgs g{};
+  g.A = w.a_hat; g.B = w.r_hat; g.D = out;
+  g.M = (int)P; g.N = (int)P; g.K = (int)C; g.nseg = 1;
+  g.a_ld = P; g.b_ld = P; g.d_ld = P;
+  g.a_bs = C * P; g.b_bs = C * P; g.d_bs = P * P;
+  g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
+  return launch_gemm<128, 128, 2, 2, false, false>(g, s, "tcl_corr4d_fwd(gemm)");
+}
+
+constexpr int ARGMAX_BN = 128;
+extern "C" size_t tcl_corr4d_argmax_flow_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P) {
+  if (B <= 0 || C <= 0 || F <= 0 || P <= 0) return 0;
+  return corr_ws(nullptr, B, C, F, P).bytes + round_up((size_t)B * F * P * cdiv(P, ARGMAX_BN) * sizeof(float2), 256);
+}
+
+extern "C" int tcl_corr4d_argmax_flow(const float *x_t, const float *v_t, const float *x_r, const float *v_r, float *flow, int64_t B,
+                                      int64_t C, int64_t F, int64_t S, void *workspace, size_t workspace_bytes, void *stream) {
+  const int64_t P = S * S;
+  int rc = corr_check("tcl_corr4d_argmax_flow", B, C, F, P, TCL_PREC_F32);
+  if (rc) return rc;
+  TCL_REQUIRE(S > 1, TCL_ERR_SHAPE, "tcl_corr4d_argmax_flow: S must be > 1");
+  TCL_REQUIRE(x_t && x_r && flow && aligned(flow, 8), TCL_ERR_ARG, "tcl_corr4d_argmax_flow: NULL / misaligned pointer");
+  const size_t need = tcl_corr4d_argmax_flow_workspace_bytes(B, C, F, P);
+  TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
+              "tcl_corr4d_argmax_flow: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  const CorrWs w = corr_ws(workspace, B, C, F, P);
+  float2 *part = (float2 *)((char *)workspace + w.bytes);
+  const dim3 blk(256);
+  hipLaunchKernelGGL(corr_normalise_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)B), blk, 0, s, x_t, v_t, w.a_hat, w.n_t, (int)C, 1, (int)P);
+  hipLaunchKernelGGL(corr_normalise_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)(B * F)), blk, 0, s, x_r, v_r, w.r_hat, w.n_r, (int)C, (int)F, (int)P);
+  rc = check_launch("tcl_corr4d_argmax_flow(normalise)");
+  if (rc) return rc;
+  GemmArgs g{};
+  g.A = w.a_hat; g.B = w.r_hat; g.D = (float *)part;
+  g.M = (int)P; g.N = (int)P; g.K = (int)C; g.nseg = 1;
+  g.a_ld = P; g.b_ld = P; g.d_ld = P;
+  g.a_bs = C * P; g.b_bs = C * P; g.d_bs = 0;
+  g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
+  rc = launch_gemm<128, ARGMAX_BN, 2, 2, false, false, EPI_ARGMAX>(g, s, "tcl_corr4d_argmax_flow(gemm)");
+  if (rc) return rc;
+  const int64_t rows = B * F * P;
+  int64_t blocks = cdiv(rows, 256);
+  if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+  hipLaunchKernelGGL(argmax_tiles_to_flow_kernel, dim3((unsigned)blocks), blk, 0, s, part, flow, rows, (int)cdiv(P, ARGMAX_BN), (int)S,
+                     (float)(2.0 / (double)(S - 1)));
+  return check_launch("tcl_corr4d_argmax_flow(reduce)");
+}
+
+extern "C" size_t tcl_corr4d_bwd_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P, int precision) {
+  (void)precision;
+  if (B <= 0 || C <= 0 || F <= 0 || P <= 0) return 0;
+  return round_up((size_t)B * C * P * 4, 256) + round_up((size_t)B * F * C * P * 4, 256);
+}
+
+extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const float *v_t, const float *x_r, const float *v_r,
+                              const void *fwd_workspace, float *g_x_t, float *g_x_r, int64_t B, int64_t C, int64_t F,
+                              int64_t P, int precision, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = corr_check("tcl_corr4d_bwd", B, C, F, P, precision);
+  if (rc) return rc;
+  TCL_REQUIRE(grad_out && x_t && x_r && fwd_workspace, TCL_ERR_ARG, "tcl_corr4d_bwd: NULL pointer");
+  TCL_REQUIRE(aligned(fwd_workspace, 256), TCL_ERR_WORKSPACE, "tcl_corr4d_bwd: fwd_workspace must be 256-byte aligned");
+  const size_t need = tcl_corr4d_bwd_workspace_bytes(B, C, F, P, precision);
+  TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
+              "tcl_corr4d_bwd: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  const CorrWs w = corr_ws(const_cast<void *>(fwd_workspace), B, C, F, P);
+  float *d_a = (float *)workspace;
+  float *d_r = (float *)((char *)workspace + round_up((size_t)B * C * P * 4, 256));
+  const dim3 blk(256);
+  if (g_x_t) {
+    // d_a^[b][c][p] = sum_f sum_q r^[b,f][c][q] G[b,f][p][q]      (M = C, N = P, K = P per reference frame)
+    GemmArgs g{};
+    g.A = w.r_hat; g.B = grad_out; g.D = d_a;
+    g.M = (int)C; g.N = (int)P; g.K = (int)P; g.nseg = (int)F;
+    g.a_ld = P; g.b_ld = P; g.d_ld = P;
+    g.a_bs = F * C * P; g.b_bs = F * P * P; g.d_bs = C * P;
+    g.a_ss = C * P; g.b_ss = P * P; g.a_bdiv = 1; g.nbatch = (int)B;
+    rc = launch_gemm<256, 128, 4, 2, true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(corr_normalise_bwd_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)B), blk, 0, s, x_t, v_t, d_a, w.n_t, g_x_t, (int)C, 1, (int)P);
+    rc = check_launch("tcl_corr4d_bwd(normalise bwd, target)");
+    if (rc) return rc;
+  }
+  if (g_x_r) {
+    // d_r^[b,f][c][q] = sum_p a^[b][c][p] G[b,f][p][q]              (M = C, N = P, K = P)
+    GemmArgs g{};
+    g.A = w.a_hat; g.B = grad_out; g.D = d_r;
+    g.M = (int)C; g.N = (int)P; g.K = (int)P; g.nseg = 1;
+    g.a_ld = P; g.b_ld = P; g.d_ld = P;
+    g.a_bs = C * P; g.b_bs = P * P; g.d_bs = C * P;
+    g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
+    rc = launch_gemm<256, 128, 4, 2, true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(corr_normalise_bwd_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)(B * F)), blk, 0, s, x_r, v_r, d_r, w.n_r, g_x_r, (int)C, (int)F, (int)P);
+    rc = check_launch("tcl_corr4d_bwd(normalise bwd, refs)");
+  }
+  return rc;
+}
+
+extern "C" int tcl_corr1x1_fwd(const float *f1, const float *f2, const float *m1, const float *m2, float *out, int64_t B,
+                               int64_t C, int64_t P, void *stream) {
+  TCL_REQUIRE(B > 0 && C > 0 && P > 0 && P < (1LL << 31) && C < (1 << 24), TCL_ERR_SHAPE, "tcl_corr1x1_fwd: bad shape");
+  TCL_REQUIRE(f1 && f2 && m1 && m2 && out, TCL_ERR_ARG, "tcl_corr1x1_fwd: NULL pointer");
+  int64_t blocks = cdiv(B * P, 256);
+  if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+  hipLaunchKernelGGL(corr1x1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f1, f2, m1, m2, out, (int)C, (int)P, B * P);
+  return check_launch("tcl_corr1x1_fwd");
+}
+
+extern "C" int tcl_corr1x1_bwd(const float *grad_out, const float *f1, const float *f2, const float *m1, const float *m2,
+                               float *g_f1, float *g_f2, int64_t B, int64_t C, int64_t P, void *stream) {
+  TCL_REQUIRE(B > 0 && C > 0 && P > 0 && P < (1LL << 31) && C < (1 << 24), TCL_ERR_SHAPE, "tcl_corr1x1_bwd: bad shape");
+  TCL_REQUIRE(grad_out && f1 && f2 && m1 && m2, TCL_ERR_ARG, "tcl_corr1x1_bwd: NULL pointer");
+  if (!g_f1 && !g_f2) return TCL_OK;
+  int64_t blocks = cdiv(B * P, 256);
+  if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+  hipLaunchKernelGGL(corr1x1_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad_out, f1, f2, m1, m2, g_f1, g_f2, (int)C, (int)P, B * P);
+  return check_launch("tcl_corr1x1_bwd");
+}
+
+extern "C" int tcl_corr_to_flow(const float *corr, float *flow, int64_t N, int64_t S, void *stream) {
+  TCL_REQUIRE(N > 0 && S > 1 && S < 32768, TCL_ERR_SHAPE, "tcl_corr_to_flow: bad shape N=%ld S=%ld", (long)N, (long)S);
+  TCL_REQUIRE(corr && flow && aligned(flow, 8), TCL_ERR_ARG, "tcl_corr_to_flow: NULL / misaligned pointer");
+  const int64_t rows = N * S * S;
+  int64_t blocks = cdiv(rows, 4);
+  if (blocks > kMaxStreamBlocks * 4) blocks = kMaxStreamBlocks * 4;
+  const float scale = (float)(2.0 / (double)(S - 1));
+  hipLaunchKernelGGL(corr_to_flow_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, corr, flow, rows, (int)S, scale);
+  return check_launch("tcl_corr_to_flow");
+}

@@ -1,0 +1,525 @@
+// Masked cross-frame context matching and aggregation (CPN "copy" step), forward and backward, gfx950.
+//
+// Replaces CPNContextMatchingDefault.forward (models/cpn.py:94-135), CPNContextMatchingComplete.forward
+// (models/cpn.py:142-195), CM_Module.forward (models/cpn_original.py:201-243), masked_softmax
+// (models/cpn.py:7-15), add_match_border / add_border (models/cpn.py:23-44) and the 3x3-cross dilation of
+// utils/transforms.py:87-105; see include/tcl.h.
+//
+// The reference builds a (B,C,R,h,w) "cos_sim" tensor that is constant over C, h and w and runs a 7-kernel
+// masked softmax over it inside a Python loop over the R reference frames.  Here the path is:
+//   resize  : v_t, v_aligned -> (bilinear > 0.5) masks at feature resolution              [bit-exact]
+//   sim     : gs[b,r] = sum_{c,x} vmap_r[x] f_t[c,x] f_r[c,x]     one pass over c_feats, wave shuffles,
+//             per-block partial sums (summed in block order: deterministic, no float atomics)
+//   finalize: v_sum, the `zeros` flag and the normalisation                                [flags bit-exact]
+//   aggregate: per pixel softmax over r (channel independent), weighted sum of the reference features,
+//             c_mask and the concatenated decoder input, written once
+// All of it is HBM-bound (0.5 flop/byte): coalesced along the pixel axis of the NCHW-like (B,C,R+1,h,w) layout.
+#include "tcl_common.h"
+
+namespace tcl {
+
+// ------------------------------------------------------------------------------------------ mask helpers
+// out[n][y][x] = bilinear(v[n], align_corners=False)(y,x) > 0.5
+__global__ void __launch_bounds__(256) resize_mask_kernel(const float *__restrict__ v, float *__restrict__ out, int64_t N,
+                                                          int H, int W, int h, int w) {
+  const float sh = __fdiv_rn((float)H, (float)h), sw = __fdiv_rn((float)W, (float)w);
+  const int64_t total = N * h * w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / (h * w);
+    const int r = (int)(i - n * h * w), y = r / w, x = r - y * w;
+    const LinTap ty = linear_tap(y, H, sh), tx = linear_tap(x, W, sw);
+    const float *p = v + n * H * W;
+    const float val = bilerp(p[ty.i0 * W + tx.i0], p[ty.i0 * W + tx.i1], p[ty.i1 * W + tx.i0], p[ty.i1 * W + tx.i1], tx, ty);
+    out[i] = val > 0.5f ? 1.f : 0.f;
+  }
+}
+
+__device__ __forceinline__ float dilate_at(const float *img, int y, int x, int H, int W) {
+  float m = img[y * W + x];
+  if (y > 0) m = fmaxf(m, img[(y - 1) * W + x]);
+  if (y < H - 1) m = fmaxf(m, img[(y + 1) * W + x]);
+  if (x > 0) m = fmaxf(m, img[y * W + x - 1]);
+  if (x < W - 1) m = fmaxf(m, img[y * W + x + 1]);
+  return m;
+}
+
+__global__ void __launch_bounds__(256) dilate_cross3_kernel(const float *__restrict__ img, float *__restrict__ out, int64_t N, int H, int W) {
+  const int64_t total = N * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / (H * W);
+    const int r = (int)(i - n * H * W), y = r / W, x = r - y * W;
+    out[i] = dilate_at(img + n * H * W, y, x, H, W);
+  }
+}
+
+// ref_importance (B,3,R+1,H,W): planes = upsampled c_match with a middle plane inserted at R/2, hole border painted red.
+__global__ void __launch_bounds__(256) ref_importance_kernel(const float *__restrict__ c_match, const float *__restrict__ v_t,
+                                                             float *__restrict__ out, int B, int R, int h, int w, int H, int W,
+                                                             int middle_is_vt) {
+  const float sh = __fdiv_rn((float)h, (float)H), sw = __fdiv_rn((float)w, (float)W);
+  const int64_t HW = (int64_t)H * W, total = (int64_t)B * (R + 1) * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bj = i / HW;
+    const int pix = (int)(i - bj * HW), y = pix / W, x = pix - y * W;
+    const int b = (int)(bj / (R + 1)), j = (int)(bj - (int64_t)b * (R + 1));
+    const float *vt = v_t + (int64_t)b * HW;
+    // border = dilate(hole) - hole > 0 with hole = 1 - v_t; dilation of (1 - v) is 1 - erosion(v)
+    const float hole = 1.f - vt[pix];
+    float dil = hole;
+    if (y > 0) dil = fmaxf(dil, 1.f - vt[pix - W]);
+    if (y < H - 1) dil = fmaxf(dil, 1.f - vt[pix + W]);
+    if (x > 0) dil = fmaxf(dil, 1.f - vt[pix - 1]);
+    if (x < W - 1) dil = fmaxf(dil, 1.f - vt[pix + 1]);
+    const float border = (dil - hole) > 0.f ? 1.f : 0.f;
+    float val;
+    if (j == R / 2) {
+      val = middle_is_vt ? vt[pix] : 0.f;
+    } else {
+      const int r = j < R / 2 ? j : j - 1;
+      const float *p = c_match + ((int64_t)b * R + r) * h * w;
+      const LinTap ty = linear_tap(y, h, sh), tx = linear_tap(x, w, sw);
+      val = bilerp(p[ty.i0 * w + tx.i0], p[ty.i0 * w + tx.i1], p[ty.i1 * w + tx.i0], p[ty.i1 * w + tx.i1], tx, ty);
+    }
+    const float keep = val * (1.f - border);
+    float *o = out + ((int64_t)b * 3 * (R + 1) + j) * HW + pix;
+    o[0] = keep + border;
+    o[(int64_t)(R + 1) * HW] = keep;
+    o[(int64_t)2 * (R + 1) * HW] = keep;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ A5 generic masked softmax
+// vec (O,R,I), mask (Om,R,I); thread per (o,i), sequential over r.
+__global__ void __launch_bounds__(256) masked_softmax_fwd_kernel(const float *__restrict__ vec, const float *__restrict__ mask,
+                                                                 float *__restrict__ out, int64_t O, int64_t Om, int R, int64_t I) {
+  const int64_t total = O * I, rep = O / Om;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = t / I, i = t - o * I;
+    const float *vp = vec + o * R * I + i, *mp = mask + (o / rep) * R * I + i;
+    float mx = -INFINITY;
+    for (int r = 0; r < R; ++r) mx = fmaxf(mx, vp[r * I] * mp[r * I]);
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += expf(vp[r * I] * mp[r * I] - mx) * mp[r * I];
+    if (s < 1e-4f) s += 1.f;
+    float *op = out + o * R * I + i;
+    for (int r = 0; r < R; ++r) op[r * I] = expf(vp[r * I] * mp[r * I] - mx) * mp[r * I] / s;
+  }
+}
+
+__global__ void __launch_bounds__(256) masked_softmax_bwd_kernel(const float *__restrict__ go, const float *__restrict__ vec,
+                                                                 const float *__restrict__ mask, float *__restrict__ gv,
+                                                                 int64_t O, int64_t Om, int R, int64_t I) {
+  const int64_t total = O * I, rep = O / Om;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = t / I, i = t - o * I;
+    const float *vp = vec + o * R * I + i, *mp = mask + (o / rep) * R * I + i, *gp = go + o * R * I + i;
+    float mx = -INFINITY;
+    int am = 0;
+    for (int r = 0; r < R; ++r) {
+      const float z = vp[r * I] * mp[r * I];
+      if (z > mx) { mx = z; am = r; }
+    }
+    float s = 0.f, ge = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const float e = expf(vp[r * I] * mp[r * I] - mx) * mp[r * I];
+      s += e;
+      ge += gp[r * I] * e;
+    }
+    const float sp = s < 1e-4f ? s + 1.f : s;
+    float tot = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const float e = expf(vp[r * I] * mp[r * I] - mx) * mp[r * I];
+      tot += (gp[r * I] / sp - ge / (sp * sp)) * e;
+    }
+    float *op = gv + o * R * I + i;
+    for (int r = 0; r < R; ++r) {
+      const float e = expf(vp[r * I] * mp[r * I] - mx) * mp[r * I];
+      float d = (gp[r * I] / sp - ge / (sp * sp)) * e;
+      if (r == am) d -= tot;
+      op[r * I] = d * mp[r * I];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ context matching
+struct CtxWs {
+  float *vt;       // (B,hw)   resized target visibility
+  float *vr;       // (B,R,hw) resized reference visibility
+  float *gs;       // (B,R)    similarity after normalisation / zeroing
+  float *dscale;   // (B,R)    d gs / d raw sum  (0 where v_sum was zero)
+  float *partial;  // (B,R,nblk) per-block partial sums of the raw similarity
+  int nblk;
+  size_t bytes;
+};
+constexpr int SIM_ITEMS = 4;  // (c,x) elements per thread in the similarity pass
+
+static CtxWs ctx_ws(void *base, int64_t B, int64_t C, int64_t R, int64_t hw) {
+  CtxWs w;
+  size_t off = 0;
+  auto take = [&](size_t n) { float *p = (float *)((char *)base + off); off += round_up(n * sizeof(float), 256); return p; };
+  w.nblk = (int)cdiv(C * hw, 256 * SIM_ITEMS);
+  w.vt = take((size_t)B * hw);
+  w.vr = take((size_t)B * R * hw);
+  w.gs = take((size_t)B * R);
+  w.dscale = take((size_t)B * R);
+  w.partial = take((size_t)B * R * w.nblk);
+  w.bytes = off;
+  return w;
+}
+
+// grid (nblk, B).  partial[b][r][blk] = sum over the block's (c,x) elements of vt*vr_r*f_t*f_r.
+__global__ void __launch_bounds__(256) ctx_sim_kernel(const float *__restrict__ cf, const float *__restrict__ vt,
+                                                      const float *__restrict__ vr, float *__restrict__ partial, int C, int R,
+                                                      int hw, int nblk) {
+  const int b = blockIdx.y;
+  const int64_t n_el = (int64_t)C * hw;
+  const float *cfb = cf + (int64_t)b * C * (R + 1) * hw;
+  const float *vtb = vt + (int64_t)b * hw, *vrb = vr + (int64_t)b * R * hw;
+  float ft[SIM_ITEMS];
+  int64_t off[SIM_ITEMS];
+  int xs[SIM_ITEMS];
+#pragma unroll
+  for (int k = 0; k < SIM_ITEMS; ++k) {
+    const int64_t e = ((int64_t)blockIdx.x * SIM_ITEMS + k) * 256 + threadIdx.x;
+    if (e < n_el) {
+      const int c = (int)(e / hw), x = (int)(e - (int64_t)c * hw);
+      off[k] = (int64_t)c * (R + 1) * hw + x;
+      xs[k] = x;
+      ft[k] = cfb[off[k]] * vtb[x];
+    } else {
+      off[k] = -1; xs[k] = 0; ft[k] = 0.f;
+    }
+  }
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int r = 0; r < R; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < SIM_ITEMS; ++k)
+      if (off[k] >= 0) s += ft[k] * vrb[(int64_t)r * hw + xs[k]] * cfb[off[k] + (int64_t)(r + 1) * hw];
+    s = wave_sum(s);
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[((int64_t)b * R + r) * nblk + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+}
+
+// one wave per (b,r): v_sum, zeros flag, normalisation.  grid = ceil(B*R/4) blocks of 4 waves.
+__global__ void __launch_bounds__(256) ctx_finalize_kernel(const float *__restrict__ vt, const float *__restrict__ vr,
+                                                           const float *__restrict__ partial, float *__restrict__ gs,
+                                                           float *__restrict__ dscale, int BR, int R, int C, int hw, int nblk,
+                                                           int variant, int normalize) {
+  const int br = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (br >= BR) return;
+  const int b = br / R;
+  const float *vtb = vt + (int64_t)b * hw, *vrb = vr + (int64_t)br * hw;
+  float vs = 0.f, raw = 0.f;
+  for (int x = lane; x < hw; x += 64) vs += vtb[x] * vrb[x];
+  for (int k = lane; k < nblk; k += 64) raw += partial[(int64_t)br * nblk + k];
+  vs = wave_sum(vs);  // a count of {0,1} products: exact in fp32 up to 2^24 pixels
+  raw = wave_sum(raw);
+  if (lane == 0) {
+    const bool zero = vs < 1e-4f;
+    const float v_sum = zero ? vs + 1.f : vs;
+    float g, ds;
+    if (variant == TCL_CTX_CM_MODULE) {        // gs / v_sum / C            (cpn_original.py:226)
+      g = (raw / v_sum) / (float)C;
+      ds = (1.f / v_sum) / (float)C;
+    } else if (normalize) {                    // gs / (v_sum * C)          (cpn.py:115-116)
+      g = raw / (v_sum * (float)C);
+      ds = 1.f / (v_sum * (float)C);
+    } else {
+      g = raw; ds = 1.f;
+    }
+    gs[br] = zero ? 0.f : g;
+    dscale[br] = zero ? 0.f : ds;
+  }
+}
+
+// block = 64 pixels x 4 channel groups; dynamic LDS = R*64 floats (softmax weights of the block's pixels).
+// grid (ceil(hw/64), B).
+__global__ void __launch_bounds__(256) ctx_aggregate_kernel(const float *__restrict__ cf, const float *__restrict__ vt,
+                                                            const float *__restrict__ vr, const float *__restrict__ gs,
+                                                            float *__restrict__ p_in, float *__restrict__ c_mask,
+                                                            float *__restrict__ c_match, int C, int R, int hw, int variant) {
+  extern __shared__ __attribute__((aligned(16))) float wts[];  // [R][64]
+  const int b = blockIdx.y, px = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int x = blockIdx.x * 64 + px;
+  const bool ok = x < hw;
+  const float *vrb = vr + (int64_t)b * R * hw;
+  const float vtx = ok ? vt[(int64_t)b * hw + x] : 0.f;
+  if (cg == 0) {
+    float cm = 0.f;
+    if (ok) {
+      const float *g = gs + (int64_t)b * R;
+      float mx = -INFINITY;
+      for (int r = 0; r < R; ++r) mx = fmaxf(mx, g[r] * vrb[(int64_t)r * hw + x]);
+      float s = 0.f;
+      for (int r = 0; r < R; ++r) {
+        const float m = vrb[(int64_t)r * hw + x];
+        s += expf(g[r] * m - mx) * m;
+      }
+      if (s < 1e-4f) s += 1.f;
+      const float hole = variant == TCL_CTX_COMPLETE ? 1.f - vtx : 1.f;
+      for (int r = 0; r < R; ++r) {
+        const float m = vrb[(int64_t)r * hw + x];
+        const float wgt = (expf(g[r] * m - mx) * m / s) * hole;
+        wts[r * 64 + px] = wgt;
+        c_match[((int64_t)b * R + r) * hw + x] = wgt;
+        cm += wgt * m;
+      }
+      cm = 1.f - cm;
+      c_mask[(int64_t)b * hw + x] = cm;
+      const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
+      p_in[((int64_t)b * (cch + 1) + cch) * hw + x] = cm;
+    } else {
+      for (int r = 0; r < R; ++r) wts[r * 64 + px] = 0.f;
+    }
+  }
+  __syncthreads();
+  if (!ok) return;
+  const float *cfb = cf + (int64_t)b * C * (R + 1) * hw + x;
+  if (variant == TCL_CTX_COMPLETE) {
+    float *o = p_in + (int64_t)b * (C + 1) * hw + x;
+    for (int c = cg; c < C; c += 4) {
+      const float *fp = cfb + (int64_t)c * (R + 1) * hw;
+      float acc = 0.f;
+      for (int r = 0; r < R; ++r) acc += fp[(int64_t)(r + 1) * hw] * wts[r * 64 + px];
+      o[(int64_t)c * hw] = fp[0] * vtx + acc;
+    }
+  } else {
+    float *o = p_in + (int64_t)b * (2 * C + 1) * hw + x;
+    for (int c = cg; c < C; c += 4) {
+      const float *fp = cfb + (int64_t)c * (R + 1) * hw;
+      float acc = 0.f;
+      for (int r = 0; r < R; ++r) acc += fp[(int64_t)(r + 1) * hw] * wts[r * 64 + px];
+      o[(int64_t)c * hw] = fp[0];
+      o[(int64_t)(C + c) * hw] = acc;
+    }
+  }
+}
+
+// ---- backward
+// Pass 1 (grid (ceil(hw/64), B), block 64 px x 4 channel groups, dynamic LDS = 4*R*64 floats):
+//   d_match[r][x] = sum_c g_out[c,x] f_r[c,x] - g_mask[x] vr_r[x]; softmax Jacobian per pixel; per-block partial of
+//   d_gs[b,r] = sum_x d_cos[r][x].
+__global__ void __launch_bounds__(256) ctx_bwd_match_kernel(const float *__restrict__ g_p_in, const float *__restrict__ g_c_mask,
+                                                            const float *__restrict__ cf, const float *__restrict__ vt,
+                                                            const float *__restrict__ vr, const float *__restrict__ gs,
+                                                            float *__restrict__ partial, int C, int R, int hw, int variant, int nbx) {
+  extern __shared__ __attribute__((aligned(16))) float dm[];  // [4][R][64]
+  const int b = blockIdx.y, px = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int x = blockIdx.x * 64 + px;
+  const bool ok = x < hw;
+  const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
+  const int out_off = variant == TCL_CTX_COMPLETE ? 0 : C;   // channel offset of g_out inside g_p_in
+  const float *gpb = g_p_in + (int64_t)b * (cch + 1) * hw + x;
+  const float *cfb = cf + (int64_t)b * C * (R + 1) * hw + x;
+  for (int r = 0; r < R; ++r) {
+    float acc = 0.f;
+    if (ok)
+      for (int c = cg; c < C; c += 4) acc += gpb[(int64_t)(out_off + c) * hw] * cfb[((int64_t)c * (R + 1) + r + 1) * hw];
+    dm[(cg * R + r) * 64 + px] = acc;
+  }
+  __syncthreads();
+  if (cg != 0) return;
+  const float *vrb = vr + (int64_t)b * R * hw;
+  const float *g = gs + (int64_t)b * R;
+  float gmask = 0.f, hole = 1.f;
+  if (ok) {
+    gmask = gpb[(int64_t)cch * hw] + (g_c_mask ? g_c_mask[(int64_t)b * hw + x] : 0.f);
+    if (variant == TCL_CTX_COMPLETE) hole = 1.f - vt[(int64_t)b * hw + x];
+  }
+  float mx = -INFINITY, s = 0.f, ge = 0.f, tot = 0.f;
+  int am = 0;
+  if (ok) {
+    for (int r = 0; r < R; ++r) {
+      const float z = g[r] * vrb[(int64_t)r * hw + x];
+      if (z > mx) { mx = z; am = r; }
+    }
+    for (int r = 0; r < R; ++r) {
+      const float m = vrb[(int64_t)r * hw + x];
+      const float e = expf(g[r] * m - mx) * m;
+      const float d = (((dm[r * 64 + px] + dm[(R + r) * 64 + px]) + (dm[(2 * R + r) * 64 + px] + dm[(3 * R + r) * 64 + px])) - gmask * m) * hole;
+      dm[r * 64 + px] = d;   // d loss / d softmax_r
+      s += e;
+      ge += d * e;
+    }
+  }
+  const float sp = s < 1e-4f ? s + 1.f : s;
+  if (ok)
+    for (int r = 0; r < R; ++r) {
+      const float m = vrb[(int64_t)r * hw + x];
+      const float e = expf(g[r] * m - mx) * m;
+      tot += (dm[r * 64 + px] / sp - ge / (sp * sp)) * e;
+    }
+  for (int r = 0; r < R; ++r) {
+    float d = 0.f;
+    if (ok) {
+      const float m = vrb[(int64_t)r * hw + x];
+      const float e = expf(g[r] * m - mx) * m;
+      d = (dm[r * 64 + px] / sp - ge / (sp * sp)) * e;
+      if (r == am) d -= tot;
+      d *= m;
+    }
+    d = wave_sum(d);  // cg == 0 is exactly wave 0
+    if (px == 0) partial[((int64_t)b * R + r) * nbx + blockIdx.x] = d;
+  }
+}
+
+// coef[b,r] = dscale[b,r] * sum_blocks partial   (one wave per (b,r))
+__global__ void __launch_bounds__(256) ctx_bwd_finalize_kernel(const float *__restrict__ partial, const float *__restrict__ dscale,
+                                                               float *__restrict__ coef, int BR, int nbx) {
+  const int br = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (br >= BR) return;
+  float s = 0.f;
+  for (int k = lane; k < nbx; k += 64) s += partial[(int64_t)br * nbx + k];
+  s = wave_sum(s);
+  if (lane == 0) coef[br] = s * dscale[br];
+}
+
+// Pass 2: thread per (c,x) of target b; writes all R+1 frames of g_c_feats.  grid (ceil(C*hw/256), B).
+__global__ void __launch_bounds__(256) ctx_bwd_feats_kernel(const float *__restrict__ g_p_in, const float *__restrict__ cf,
+                                                            const float *__restrict__ c_match, const float *__restrict__ vt,
+                                                            const float *__restrict__ vr, const float *__restrict__ coef,
+                                                            float *__restrict__ g_cf, int C, int R, int hw, int variant) {
+  const int b = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)C * hw) return;
+  const int c = (int)(e / hw), x = (int)(e - (int64_t)c * hw);
+  const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
+  const float *gpb = g_p_in + (int64_t)b * (cch + 1) * hw + x;
+  const float vtx = vt[(int64_t)b * hw + x];
+  float g_ft, g_out;
+  if (variant == TCL_CTX_COMPLETE) {
+    g_out = gpb[(int64_t)c * hw];
+    g_ft = g_out * vtx;
+  } else {
+    g_ft = gpb[(int64_t)c * hw];
+    g_out = gpb[(int64_t)(C + c) * hw];
+  }
+  const int64_t base = ((int64_t)b * C + c) * (R + 1) * hw + x;
+  const float ft = cf[base];
+  for (int r = 0; r < R; ++r) {
+    const float k = coef[b * R + r] * (vtx * vr[((int64_t)b * R + r) * hw + x]);
+    const float fr = cf[base + (int64_t)(r + 1) * hw];
+    g_ft += k * fr;
+    g_cf[base + (int64_t)(r + 1) * hw] = g_out * c_match[((int64_t)b * R + r) * hw + x] + k * ft;
+  }
+  g_cf[base] = g_ft;
+}
+
+static unsigned stream_blocks(int64_t total) {
+  int64_t blocks = cdiv(total, 256);
+  if (blocks > kMaxStreamBlocks * 2) blocks = kMaxStreamBlocks * 2;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+}  // namespace tcl
+
+using namespace tcl;
+
+// ============================================================================================ C ABI
+extern "C" int tcl_resize_mask(const float *v, float *out, int64_t N, int64_t H, int64_t W, int64_t h, int64_t w, void *stream) {
+  TCL_REQUIRE(N > 0 && H > 0 && W > 0 && h > 0 && w > 0 && H * W < (1LL << 31) && h * w < (1LL << 31), TCL_ERR_SHAPE, "tcl_resize_mask: bad shape");
+  TCL_REQUIRE(v && out, TCL_ERR_ARG, "tcl_resize_mask: NULL pointer");
+  hipLaunchKernelGGL(resize_mask_kernel, dim3(stream_blocks(N * h * w)), dim3(256), 0, (hipStream_t)stream, v, out, N, (int)H, (int)W, (int)h, (int)w);
+  return check_launch("tcl_resize_mask");
+}
+
+extern "C" int tcl_dilate_cross3(const float *img, float *out, int64_t N, int64_t H, int64_t W, void *stream) {
+  TCL_REQUIRE(N > 0 && H > 0 && W > 0 && H * W < (1LL << 31), TCL_ERR_SHAPE, "tcl_dilate_cross3: bad shape");
+  TCL_REQUIRE(img && out && img != out, TCL_ERR_ARG, "tcl_dilate_cross3: NULL pointer or in-place call");
+  hipLaunchKernelGGL(dilate_cross3_kernel, dim3(stream_blocks(N * H * W)), dim3(256), 0, (hipStream_t)stream, img, out, N, (int)H, (int)W);
+  return check_launch("tcl_dilate_cross3");
+}
+
+extern "C" int tcl_ref_importance(const float *c_match, const float *v_t, float *ref_importance, int64_t B, int64_t R, int64_t h,
+                                  int64_t w, int64_t H, int64_t W, int middle_is_vt, void *stream) {
+  TCL_REQUIRE(B > 0 && R > 0 && h > 0 && w > 0 && H > 0 && W > 0 && H * W < (1LL << 31), TCL_ERR_SHAPE, "tcl_ref_importance: bad shape");
+  TCL_REQUIRE(c_match && v_t && ref_importance, TCL_ERR_ARG, "tcl_ref_importance: NULL pointer");
+  hipLaunchKernelGGL(ref_importance_kernel, dim3(stream_blocks(B * (R + 1) * H * W)), dim3(256), 0, (hipStream_t)stream, c_match, v_t,
+                     ref_importance, (int)B, (int)R, (int)h, (int)w, (int)H, (int)W, middle_is_vt);
+  return check_launch("tcl_ref_importance");
+}
+
+extern "C" int tcl_masked_softmax_fwd(const float *vec, const float *mask, float *out, int64_t O, int64_t Om, int64_t R, int64_t I, void *stream) {
+  TCL_REQUIRE(O > 0 && Om > 0 && R > 0 && I > 0 && O % Om == 0 && R < (1 << 20), TCL_ERR_SHAPE, "tcl_masked_softmax_fwd: bad shape O=%ld Om=%ld R=%ld I=%ld", (long)O, (long)Om, (long)R, (long)I);
+  TCL_REQUIRE(vec && mask && out, TCL_ERR_ARG, "tcl_masked_softmax_fwd: NULL pointer");
+  hipLaunchKernelGGL(masked_softmax_fwd_kernel, dim3(stream_blocks(O * I)), dim3(256), 0, (hipStream_t)stream, vec, mask, out, O, Om, (int)R, I);
+  return check_launch("tcl_masked_softmax_fwd");
+}
+
+extern "C" int tcl_masked_softmax_bwd(const float *grad_out, const float *vec, const float *mask, float *g_vec, int64_t O, int64_t Om, int64_t R, int64_t I, void *stream) {
+  TCL_REQUIRE(O > 0 && Om > 0 && R > 0 && I > 0 && O % Om == 0 && R < (1 << 20), TCL_ERR_SHAPE, "tcl_masked_softmax_bwd: bad shape");
+  TCL_REQUIRE(grad_out && vec && mask && g_vec, TCL_ERR_ARG, "tcl_masked_softmax_bwd: NULL pointer");
+  hipLaunchKernelGGL(masked_softmax_bwd_kernel, dim3(stream_blocks(O * I)), dim3(256), 0, (hipStream_t)stream, grad_out, vec, mask, g_vec, O, Om, (int)R, I);
+  return check_launch("tcl_masked_softmax_bwd");
+}
+
+static int ctx_check(const char *fn, int64_t B, int64_t C, int64_t R, int64_t h, int64_t w, int variant) {
+  TCL_REQUIRE(B > 0 && C > 0 && R > 0 && h > 0 && w > 0, TCL_ERR_SHAPE, "%s: bad shape B=%ld C=%ld R=%ld h=%ld w=%ld", fn, (long)B, (long)C, (long)R, (long)h, (long)w);
+  TCL_REQUIRE(B < 65536 && h * w < (1 << 24) && C * h * w < (1LL << 31) && R <= 64, TCL_ERR_SHAPE, "%s: shape out of range (R <= 64, B < 65536)", fn);
+  TCL_REQUIRE(variant >= TCL_CTX_DEFAULT && variant <= TCL_CTX_CM_MODULE, TCL_ERR_ARG, "%s: unknown variant %d", fn, variant);
+  return TCL_OK;
+}
+
+extern "C" size_t tcl_ctx_workspace_bytes(int64_t B, int64_t C, int64_t R, int64_t h, int64_t w) {
+  if (B <= 0 || C <= 0 || R <= 0 || h <= 0 || w <= 0) return 0;
+  return ctx_ws(nullptr, B, C, R, h * w).bytes;
+}
+
+extern "C" int tcl_ctx_fwd(const float *c_feats, const float *v_t, const float *v_aligned, float *p_in, float *c_mask, float *c_match,
+                           int64_t B, int64_t C, int64_t R, int64_t h, int64_t w, int64_t H, int64_t W, int variant, int normalize,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = ctx_check("tcl_ctx_fwd", B, C, R, h, w, variant);
+  if (rc) return rc;
+  TCL_REQUIRE(H > 0 && W > 0 && H * W < (1LL << 31), TCL_ERR_SHAPE, "tcl_ctx_fwd: bad mask shape");
+  TCL_REQUIRE(c_feats && v_t && v_aligned && p_in && c_mask && c_match, TCL_ERR_ARG, "tcl_ctx_fwd: NULL pointer");
+  const size_t need = tcl_ctx_workspace_bytes(B, C, R, h, w);
+  TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
+              "tcl_ctx_fwd: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  const int hw = (int)(h * w);
+  const CtxWs ws = ctx_ws(workspace, B, C, R, hw);
+  hipLaunchKernelGGL(resize_mask_kernel, dim3(stream_blocks(B * hw)), dim3(256), 0, s, v_t, ws.vt, B, (int)H, (int)W, (int)h, (int)w);
+  hipLaunchKernelGGL(resize_mask_kernel, dim3(stream_blocks(B * R * hw)), dim3(256), 0, s, v_aligned, ws.vr, B * R, (int)H, (int)W, (int)h, (int)w);
+  hipLaunchKernelGGL(ctx_sim_kernel, dim3(ws.nblk, (unsigned)B), dim3(256), 0, s, c_feats, ws.vt, ws.vr, ws.partial, (int)C, (int)R, hw, ws.nblk);
+  hipLaunchKernelGGL(ctx_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, ws.vt, ws.vr, ws.partial, ws.gs, ws.dscale,
+                     (int)(B * R), (int)R, (int)C, hw, ws.nblk, variant, normalize);
+  hipLaunchKernelGGL(ctx_aggregate_kernel, dim3((unsigned)cdiv(hw, 64), (unsigned)B), dim3(256), (size_t)R * 64 * sizeof(float), s, c_feats,
+                     ws.vt, ws.vr, ws.gs, p_in, c_mask, c_match, (int)C, (int)R, hw, variant);
+  return check_launch("tcl_ctx_fwd");
+}
+
+extern "C" size_t tcl_ctx_bwd_workspace_bytes(int64_t B, int64_t C, int64_t R, int64_t h, int64_t w) {
+  (void)C;
+  if (B <= 0 || R <= 0 || h <= 0 || w <= 0) return 0;
+  return round_up((size_t)B * R * cdiv(h * w, 64) * 4, 256) + round_up((size_t)B * R * 4, 256);
+}
+
+extern "C" int tcl_ctx_bwd(const float *g_p_in, const float *g_c_mask, const float *c_feats, const float *c_match, const void *fwd_workspace,
+                           float *g_c_feats, int64_t B, int64_t C, int64_t R, int64_t h, int64_t w, int variant, int normalize,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+  (void)normalize;  // already folded into the forward's dscale
+  int rc = ctx_check("tcl_ctx_bwd", B, C, R, h, w, variant);
+  if (rc) return rc;
+  TCL_REQUIRE(g_p_in && c_feats && c_match && fwd_workspace && g_c_feats, TCL_ERR_ARG, "tcl_ctx_bwd: NULL pointer");
+  TCL_REQUIRE(aligned(fwd_workspace, 256), TCL_ERR_WORKSPACE, "tcl_ctx_bwd: fwd_workspace must be 256-byte aligned");
+  const size_t need = tcl_ctx_bwd_workspace_bytes(B, C, R, h, w);
+  TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
+              "tcl_ctx_bwd: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  const int hw = (int)(h * w), nbx = (int)cdiv(hw, 64);
+  const CtxWs ws = ctx_ws(const_cast<void *>(fwd_workspace), B, C, R, hw);
+  float *partial = (float *)workspace;
+  float *coef = (float *)((char *)workspace + round_up((size_t)B * R * nbx * 4, 256));
+  hipLaunchKernelGGL(ctx_bwd_match_kernel, dim3(nbx, (unsigned)B), dim3(256), (size_t)4 * R * 64 * sizeof(float), s, g_p_in, g_c_mask, c_feats,
+                     ws.vt, ws.vr, ws.gs, partial, (int)C, (int)R, hw, variant, nbx);
+  hipLaunchKernelGGL(ctx_bwd_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, partial, ws.dscale, coef, (int)(B * R), nbx);
+  hipLaunchKernelGGL(ctx_bwd_feats_kernel, dim3((unsigned)cdiv(C * hw, 256), (unsigned)B), dim3(256), 0, s, g_p_in, c_feats, c_match, ws.vt,
+                     ws.vr, coef, g_c_feats, (int)C, (int)R, hw, variant);
+  return check_launch("tcl_ctx_bwd");
+}

@@ -1,0 +1,319 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the drop-in modules) against
+  (1) the golden vectors captured from the real reference (tests/golden/*.npz) and
+  (2) the numpy oracle on seeded inputs at sizes it finishes in seconds,
+with the bars of BASELINE.json: fp32 within 1e-4 relative, masks / indices bit-exact.
+Run on the GPU box:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tcl_oracle as O
+from tests.conftest import assert_close, assert_exact, load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a, grad=False):
+    if a is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+def N(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from master_thesis_amd.models import cpn, cpn_original
+    from master_thesis_amd.utils import correlation, flow
+    return dict(corr=correlation, flow=flow, cpn=cpn, cpo=cpn_original)
+
+
+# ------------------------------------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("case", load_golden("corr4d"))
+def test_golden_corr4d(mods, case):
+    xt, xr = T(case["x_t"], True), T(case["x_r"], True)
+    out = mods["corr"].compute_masked_4d_correlation(xt, T(case.get("v_t")), xr, T(case.get("v_r")))
+    assert_close(N(out), case["out"], what="corr4d fwd")
+    gt, gr = torch.autograd.grad((out * T(case["cot"])).sum(), [xt, xr])
+    assert_close(N(gt), case["g_x_t"], what="corr4d g_x_t")
+    assert_close(N(gr), case["g_x_r"], what="corr4d g_x_r")
+
+
+@pytest.mark.parametrize("case", load_golden("corr1x1"))
+def test_golden_corr1x1(mods, case):
+    f1, f2 = T(case["f1"], True), T(case["f2"], True)
+    out = mods["corr"].compute_masked_correlation(f1, f2, T(case["m1"]), T(case["m2"]))
+    assert_close(N(out), case["out"], what="corr1x1 fwd")
+    g1, g2 = torch.autograd.grad((out * T(case["cot"])).sum(), [f1, f2])
+    assert_close(N(g1), case["g_f1"], what="corr1x1 g1")
+    assert_close(N(g2), case["g_f2"], what="corr1x1 g2")
+
+
+@pytest.mark.parametrize("case", load_golden("align_set"))
+def test_golden_align_set(mods, case):
+    x, flow = T(case["x"], True), T(case["flow"], True)
+    xa, va = mods["flow"].align_set(x, T(case["v"]), flow)
+    assert xa.shape == case["x_aligned"].shape and va.shape == case["v_aligned"].shape
+    assert_close(N(xa), case["x_aligned"], what="align_set x")
+    assert_exact(N(va), case["v_aligned"], what="align_set v")
+    gx, gf = torch.autograd.grad((xa * T(case["cot"])).sum(), [x, flow])
+    assert_close(N(gx), case["g_x"], what="align_set g_x")
+    assert_close(N(gf), case["g_flow"], what="align_set g_flow")
+
+
+@pytest.mark.parametrize("case", load_golden("cpn_align"))
+def test_golden_cpn_align(mods, case):
+    r_list = [int(i) for i in case["r_list"]]
+    x, theta = T(case["x"], True), T(case["theta"], True)
+    xa, va, ya = mods["cpn"].affine_align(x, T(case["m"]), T(case["y"]), theta, r_list, training=False)
+    assert_close(N(xa), case["x_aligned"], what="cpn_align x")
+    assert_close(N(ya), case["y_aligned"], what="cpn_align y")
+    assert_exact(N(va), case["v_aligned"], what="cpn_align v")
+    gx, gth = torch.autograd.grad((xa * T(case["cot"])).sum(), [x, theta])
+    assert_close(N(gx), case["g_x"], what="cpn_align g_x")
+    assert_close(N(gth), case["g_theta"], atol=2e-5, what="cpn_align g_theta")
+
+
+@pytest.mark.parametrize("case", load_golden("masked_softmax"))
+def test_golden_masked_softmax(mods, case):
+    vec = T(case["vec"], True)
+    out = mods["cpn"].masked_softmax(vec, T(case["mask"]), 2)
+    assert_close(N(out), case["out"], what="masked_softmax")
+    (g,) = torch.autograd.grad((out * T(case["cot"])).sum(), [vec])
+    assert_close(N(g), case["g_vec"], what="masked_softmax bwd")
+    out2 = mods["cpo"].CM_Module().masked_softmax(vec, T(case["mask"]), 2)
+    assert_exact(N(out2), N(out))
+
+
+@pytest.mark.parametrize("case", load_golden("mask_resize"))
+def test_golden_mask_resize(case):
+    from master_thesis_amd import _ops
+    out = _ops.resize_mask(T(case["v"].astype(np.float32)), tuple(int(s) for s in case["size"]))
+    assert_exact(N(out).astype(np.uint8), case["out"], what="mask resize")
+
+
+@pytest.mark.parametrize("case", load_golden("context_matching"))
+def test_golden_context_matching(mods, case):
+    variant, normalize = str(case["variant"]), bool(case["normalize"])
+    cf = T(case["c_feats"], True)
+    v_t, v_al = T(case["v_t"]), T(case["v_aligned"])
+    if variant == "default":
+        p_in, c_mask, ref_imp = mods["cpn"].CPNContextMatchingDefault()(cf, v_t, v_al, normalize=normalize)
+    elif variant == "complete":
+        p_in, c_mask, ref_imp = mods["cpn"].CPNContextMatchingComplete()(cf, v_t, v_al, normalize=normalize)
+    else:
+        p_in, c_mask = mods["cpo"].CM_Module()(cf, v_t, v_al)
+        ref_imp = None
+    assert_close(N(p_in), case["p_in"], what="%s p_in" % variant)
+    assert_close(N(c_mask), case["c_mask"], what="%s c_mask" % variant)
+    if ref_imp is not None:
+        assert_close(N(ref_imp), case["ref_importance"], what="%s ref_importance" % variant)
+    (g,) = torch.autograd.grad((p_in * T(case["cot_p_in"])).sum() + (c_mask * T(case["cot_c_mask"])).sum(), [cf])
+    assert_close(N(g), case["g_c_feats"], what="%s g_c_feats" % variant)
+
+
+@pytest.mark.parametrize("case", load_golden("flow_utils"))
+def test_golden_flow_utils(mods, case):
+    op, fl = str(case["op"]), mods["flow"]
+    if op == "corr_to_flow":
+        assert_exact(N(fl.corr_to_flow(T(case["corr"]))), case["out"], what=op)
+    elif op == "flow_abs_to_relative":
+        assert_close(N(fl.flow_abs_to_relative(T(case["flow"]))), case["out"], atol=1e-6, what=op)
+    elif op == "flow_relative_to_abs":
+        assert_close(N(fl.flow_relative_to_abs(T(case["flow"]))), case["out"], atol=1e-6, what=op)
+    elif op == "crop_flow":
+        flow = T(case["flow"])
+        out = fl.crop_flow(flow, tuple(int(s) for s in case["crop_size"]), tuple(int(s) for s in case["crop_position"]))
+        assert_close(N(out), case["out"], atol=1e-6, what=op)
+    elif op == "resize_flow":
+        assert_exact(N(fl.resize_flow(T(case["flow"]), tuple(int(s) for s in case["size"]))), case["out"], what=op)
+
+
+def test_dilate_and_add_border(mods):
+    rng = np.random.default_rng(5)
+    mask = (rng.random((2, 1, 13, 17)) < 0.3).astype(np.float32)
+    from master_thesis_amd import _ops
+    assert_exact(N(_ops.dilate_cross3(T(mask))), O.dilate_cross3(mask), what="dilate")
+    x = rng.random((2, 3, 4, 13, 17)).astype(np.float32)
+    got = N(mods["cpn"].add_border(T(x), T(mask)))
+    border = ((O.dilate_cross3(mask) - mask) > 0).astype(np.float32)[:, :, None]
+    ref = x * (1 - border)
+    ref[:, 0:1] += border
+    assert_close(got, ref, what="add_border")
+
+
+# ------------------------------------------------------------------------------------------------ oracle, seeded, larger
+def _masks(rng, shape, p=0.9):
+    return (rng.random(shape) < p).astype(np.float32)
+
+
+@pytest.mark.parametrize("B,C,F,H,W,masked", [
+    (2, 64, 2, 16, 16, True),      # aligned fast path
+    (1, 512, 4, 16, 16, True),     # the alignment model's shape (C1 / C3 of BASELINE.json)
+    (2, 37, 3, 9, 7, True),        # ragged everything (scalar staging path, partial tiles)
+    (1, 256, 1, 64, 64, False),    # one pair of C2
+    (1, 20, 2, 24, 20, True),      # P % 128 != 0 with vector loads
+])
+def test_corr4d_vs_oracle(mods, B, C, F, H, W, masked):
+    rng = np.random.default_rng(B * 1000 + C)
+    xt = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    xr = rng.standard_normal((B, C, F, H, W)).astype(np.float32)
+    vt = _masks(rng, (B, 1, H, W)) if masked else None
+    vr = _masks(rng, (B, 1, F, H, W)) if masked else None
+    cot = rng.standard_normal((B, F, H, W, H, W)).astype(np.float32)
+    txt, txr = T(xt, True), T(xr, True)
+    out = mods["corr"].compute_masked_4d_correlation(txt, T(vt), txr, T(vr))
+    assert_close(N(out), O.compute_masked_4d_correlation(xt, vt, xr, vr), what="corr4d fwd")
+    gt, gr = torch.autograd.grad((out * T(cot)).sum(), [txt, txr])
+    ogt, ogr = O.compute_masked_4d_correlation_bwd(xt, vt, xr, vr, cot)
+    assert_close(N(gt), ogt, what="corr4d g_x_t")
+    assert_close(N(gr), ogr, what="corr4d g_x_r")
+
+
+def test_corr4d_properties_full_size(mods):
+    """C2 shape (64x64, C=256): self-correlation has a unit diagonal and is symmetric; masked pixels give zero rows."""
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(2, 256, 64, 64, generator=g).to(DEV)
+    v = (torch.rand(2, 1, 64, 64, generator=g) < 0.9).float().to(DEV)
+    out = mods["corr"].compute_masked_4d_correlation(x, v, x.unsqueeze(2), v.unsqueeze(2)).reshape(2, 4096, 4096)
+    vis = v.reshape(2, 4096)
+    diag = torch.diagonal(out, dim1=1, dim2=2)
+    assert torch.allclose(diag[vis > 0], torch.ones_like(diag[vis > 0]), atol=1e-5)
+    assert torch.equal(diag[vis == 0], torch.zeros_like(diag[vis == 0]))
+    assert torch.allclose(out, out.transpose(1, 2), atol=1e-6)
+    assert float(out.abs().max()) <= 1.0 + 1e-5
+    assert torch.equal(out[0][vis[0] == 0], torch.zeros_like(out[0][vis[0] == 0]))
+
+
+@pytest.mark.parametrize("B,C,F,S", [(2, 32, 2, 8), (1, 64, 1, 16), (1, 256, 1, 64), (2, 19, 3, 5)])
+def test_fused_argmax_flow(mods, B, C, F, S):
+    """corr4d + corr_to_flow fused == corr_to_flow(corr4d(...)) exactly (same arithmetic), and == the oracle wherever the
+    two best similarities are separated by more than fp32 noise."""
+    from master_thesis_amd import _ops
+    rng = np.random.default_rng(S)
+    xt = rng.standard_normal((B, C, S, S)).astype(np.float32)
+    xr = rng.standard_normal((B, C, F, S, S)).astype(np.float32)
+    vt, vr = _masks(rng, (B, 1, S, S)), _masks(rng, (B, 1, F, S, S))
+    fused = N(_ops.corr4d_argmax_flow(T(xt), T(vt), T(xr), T(vr)))
+    vol = mods["corr"].compute_masked_4d_correlation(T(xt), T(vt), T(xr), T(vr))
+    assert_exact(fused, N(mods["flow"].corr_to_flow(vol)), what="fused vs unfused")
+    ovol = O.compute_masked_4d_correlation(xt, vt, xr, vr)
+    oflow = O.corr_to_flow(ovol)
+    top2 = np.sort(ovol.reshape(B, F, S, S, S * S), axis=-1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 1e-5
+    assert clear.mean() > 0.8
+    assert_exact(fused[clear], oflow[clear], what="fused vs oracle (clear maxima)")
+
+
+@pytest.mark.parametrize("B,F,H,W,amp", [(4, 4, 64, 64, 0.3), (2, 4, 256, 256, 0.2), (3, 1, 33, 47, 1.0), (2, 2, 16, 16, 0.5)])
+def test_align_set_vs_oracle(mods, B, F, H, W, amp):
+    rng = np.random.default_rng(H + W)
+    x = rng.random((B, 3, F, H, W)).astype(np.float32)
+    v = _masks(rng, (B, 1, F, H, W), 0.8)
+    ident = np.stack(np.meshgrid(np.linspace(-1, 1, W), np.linspace(-1, 1, H)), axis=-1).astype(np.float32)
+    flow = (ident[None, None] + amp * (rng.random((B, F, H, W, 2)) * 2 - 1)).astype(np.float32)
+    cot = rng.standard_normal((B, 3, F, H, W)).astype(np.float32)
+    tx, tf = T(x, True), T(flow, True)
+    xa, va = mods["flow"].align_set(tx, T(v), tf)
+    oxa, ova = O.align_set(x, v, flow)
+    assert_close(N(xa), oxa, what="align_set x")
+    assert_exact(N(va), ova, what="align_set v")
+    gx, gf = torch.autograd.grad((xa * T(cot)).sum(), [tx, tf])
+    ogx, ogf = O.align_set_bwd(x, v, flow, cot)
+    assert_close(N(gx), ogx, what="align_set g_x")
+    assert_close(N(gf), ogf, what="align_set g_flow")
+    # T1: v_map
+    from master_thesis_amd import _ops
+    vt = _masks(rng, (B, 1, H, W), 0.8)
+    assert_exact(N(_ops.vmap(va, T(vt))), O.v_map(ova, vt), what="v_map")
+
+
+def test_align_set_strided_inputs(mods):
+    """The runners pass views (x[:, :, r_list], 1 - m[...]): non-contiguous frames must give the same result."""
+    rng = np.random.default_rng(11)
+    x = rng.random((2, 3, 5, 20, 24)).astype(np.float32)
+    v = _masks(rng, (2, 1, 5, 20, 24), 0.8)
+    flow = (rng.random((2, 4, 20, 24, 2)) * 2.4 - 1.2).astype(np.float32)
+    r_list = [0, 1, 3, 4]
+    tx, tv = T(x), T(v)
+    xa, va = mods["flow"].align_set(tx[:, :, r_list], tv[:, :, r_list], T(flow))
+    oxa, ova = O.align_set(x[:, :, r_list], v[:, :, r_list], flow)
+    assert_close(N(xa), oxa)
+    assert_exact(N(va), ova)
+    xa2, va2 = mods["flow"].align_set(tx[:, :, ::2], tv[:, :, ::2], T(flow[:, :3]))   # strided slice: planes stay dense
+    oxa2, ova2 = O.align_set(x[:, :, ::2], v[:, :, ::2], flow[:, :3])
+    assert_close(N(xa2), oxa2)
+    assert_exact(N(va2), ova2)
+
+
+def test_cpn_align_c4_shape(mods):
+    """C4: 240x424 frames, 10 references, theta = identity + noise."""
+    rng = np.random.default_rng(4)
+    B, R, H, W = 2, 10, 240, 424
+    x = rng.random((B, 3, R + 1, H, W)).astype(np.float32)
+    m = 1 - np.repeat(np.repeat(_masks(rng, (B, 1, R + 1, H // 8, W // 8), 0.7), 8, axis=3), 8, axis=4)
+    r_list = [i for i in range(R + 1) if i != R // 2]
+    theta = (np.array([[1, 0, 0], [0, 1, 0]], np.float32)[None] + 0.05 * rng.standard_normal((B * R, 2, 3))).astype(np.float32)
+    tx, tth = T(x, True), T(theta, True)
+    xa, va, ya = mods["cpn"].affine_align(tx, T(m), None, tth, r_list, training=True)
+    oxa, ova, _ = O.cpn_align(x, m, None, theta, r_list)
+    assert ya is None
+    assert_close(N(xa), oxa, what="cpn_align x")
+    got_v = N(va)
+    # bit-exact away from the 0.5 threshold; a sample whose bilinear value sits within fp32 noise of 0.5 may legally flip
+    mism = got_v != ova
+    assert mism.mean() < 1e-5, "v_aligned mismatches: %d" % mism.sum()
+    cot = rng.standard_normal(oxa.shape).astype(np.float32)
+    gx, gth = torch.autograd.grad((xa * T(cot)).sum(), [tx, tth])
+    ogx, ogth = O.cpn_align_bwd(x, theta, r_list, cot)
+    assert_close(N(gx), ogx, what="cpn_align g_x")
+    assert_close(N(gth), ogth, rtol=1e-3, atol=1e-3, what="cpn_align g_theta (sum over 101,760 pixels)")
+
+
+@pytest.mark.parametrize("variant", ["default", "complete", "cm_module"])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_context_matching_c4_shape(mods, variant, normalize):
+    """C4: c_feats (B,128,11,30,53), masks 240x424."""
+    if variant == "cm_module" and not normalize:
+        pytest.skip("CM_Module always normalises")
+    rng = np.random.default_rng(40)
+    B, C, R, h, w, H, W = 2, 128, 10, 30, 53, 240, 424
+    scale = 0.05 if not normalize else 1.0     # keep exp() of un-normalised similarities in a testable range
+    cf = (scale * rng.standard_normal((B, C, R + 1, h, w))).astype(np.float32)
+    v_t = np.repeat(np.repeat(_masks(rng, (B, 1, H // 4, W // 4), 0.6), 4, axis=2), 4, axis=3)
+    v_al = np.repeat(np.repeat(_masks(rng, (B, 1, R, H // 4, W // 4), 0.7), 4, axis=3), 4, axis=4)
+    v_al[0, :, 3] = 0
+    tcf = T(cf, True)
+    if variant == "default":
+        p_in, c_mask, ref_imp = mods["cpn"].CPNContextMatchingDefault()(tcf, T(v_t), T(v_al), normalize=normalize)
+    elif variant == "complete":
+        p_in, c_mask, ref_imp = mods["cpn"].CPNContextMatchingComplete()(tcf, T(v_t), T(v_al), normalize=normalize)
+    else:
+        p_in, c_mask = mods["cpo"].CM_Module()(tcf, T(v_t), T(v_al))
+        ref_imp = None
+    op, om, oimp = O.context_matching(cf, v_t, v_al, normalize, variant)
+    assert_close(N(p_in), op, what="p_in")
+    assert_close(N(c_mask), om, what="c_mask")
+    if ref_imp is not None:
+        assert_close(N(ref_imp), oimp, what="ref_importance")
+    cot1 = rng.standard_normal(op.shape).astype(np.float32)
+    cot2 = rng.standard_normal(om.shape).astype(np.float32)
+    (g,) = torch.autograd.grad((p_in * T(cot1)).sum() + (c_mask * T(cot2)).sum(), [tcf])
+    og = O.context_matching_bwd(cf, v_t, v_al, cot1, cot2, normalize, variant)
+    assert_close(N(g), og, rtol=1e-3, atol=1e-4, what="g_c_feats (203,520-term sums)")
+
+
+def test_errors_are_loud(mods):
+    from master_thesis_amd import TclError
+    with pytest.raises(TclError):
+        mods["corr"].compute_masked_4d_correlation(torch.zeros(1, 2, 2, 2), None, torch.zeros(1, 2, 1, 2, 2), None)
+    with pytest.raises(ValueError):
+        mods["corr"].compute_masked_4d_correlation(torch.zeros(1, 2, 2, 2, device=DEV), None, torch.zeros(1, 2, 2, device=DEV), None)
+    with pytest.raises(TclError):
+        mods["flow"].crop_flow(torch.zeros(1, 1, 4, 4, 2, device=DEV), (3, 3), (2, 2))
