@@ -79,6 +79,11 @@ int tcl_corr4d_fwd(const float *x_t, const float *v_t, const float *x_r, const f
                    int64_t B, int64_t C, int64_t F, int64_t P, int precision,
                    void *workspace, size_t workspace_bytes, void *stream);
 
+/*   The contraction step alone: out = a^T r^ from the normalised operands a previous tcl_corr4d_fwd left in
+ *   `fwd_workspace` (same B,C,F,P,precision).  Lets a caller re-materialise the volume without re-normalising. */
+int tcl_corr4d_contract(const void *fwd_workspace, float *out, int64_t B, int64_t C, int64_t F, int64_t P,
+                        int precision, void *stream);
+
 /*   grad_out (B,F,P,P) -> g_x_t (B,C,P), g_x_r (B,C,F,P) (either may be NULL to skip it).
  *   Autograd of the same reference function (the reference never differentiates it; the oracle is
  *   torch.autograd over it, see tests/golden/make_golden.py). */

@@ -22,6 +22,7 @@ SIGNATURES = {
     "tcl_last_error": (_c.c_char_p, []),
     "tcl_corr4d_fwd_workspace_bytes": (_SZ, [_I64] * 4 + [_INT]),
     "tcl_corr4d_fwd": (_INT, [_P] * 5 + [_I64] * 4 + [_INT, _P, _SZ, _P]),
+    "tcl_corr4d_contract": (_INT, [_P] * 2 + [_I64] * 4 + [_INT, _P]),
     "tcl_corr4d_bwd_workspace_bytes": (_SZ, [_I64] * 4 + [_INT]),
     "tcl_corr4d_bwd": (_INT, [_P] * 8 + [_I64] * 4 + [_INT, _P, _SZ, _P]),
     "tcl_corr4d_argmax_flow_workspace_bytes": (_SZ, [_I64] * 4),

@@ -447,13 +447,22 @@ extern "C" int tcl_corr4d_fwd(const float *x_t, const float *v_t, const float *x
   hipLaunchKernelGGL(corr_normalise_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)(B * F)), blk, 0, s, x_r, v_r, w.r_hat, w.n_r, (int)C, (int)F, (int)P);
   rc = check_launch("tcl_corr4d_fwd(normalise)");
   if (rc) return rc;
+  return tcl_corr4d_contract(workspace, out, B, C, F, P, precision, stream);
+}
+
+extern "C" int tcl_corr4d_contract(const void *fwd_workspace, float *out, int64_t B, int64_t C, int64_t F, int64_t P, int precision,
+                                   void *stream) {
+  int rc = corr_check("tcl_corr4d_contract", B, C, F, P, precision);
+  if (rc) return rc;
+  TCL_REQUIRE(fwd_workspace && aligned(fwd_workspace, 256) && out, TCL_ERR_ARG, "tcl_corr4d_contract: NULL / misaligned pointer");
+  const CorrWs w = corr_ws(const_cast<void *>(fwd_workspace), B, C, F, P);
   GemmArgs g{};
   g.A = w.a_hat; g.B = w.r_hat; g.D = out;
   g.M = (int)P; g.N = (int)P; g.K = (int)C; g.nseg = 1;
   g.a_ld = P; g.b_ld = P; g.d_ld = P;
   g.a_bs = C * P; g.b_bs = C * P; g.d_bs = P * P;
   g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
-  return launch_gemm<128, 128, 2, 2, false, false>(g, s, "tcl_corr4d_fwd(gemm)");
+  return launch_gemm<128, 128, 2, 2, false, false>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
 }
 
 constexpr int ARGMAX_BN = 128;

@@ -72,8 +72,8 @@ def compute_masked_4d_correlation_bwd(x_target_feats, v_target, x_ref_feats, v_r
     a_hat, n_t = _normalise_over_c(t)
     r_hat, n_r = _normalise_over_c(r)
     g = _f(grad_out).reshape(b, f, p, p)
-    d_a = np.einsum("bfpq,bfcq->bcp", g, r_hat).astype(F32)        # sum over refs and ref pixels
-    d_r = np.einsum("bfpq,bcp->bfcq", g, a_hat).astype(F32)
+    d_a = np.matmul(r_hat, g.transpose(0, 1, 3, 2)).sum(axis=1, dtype=F32)   # (B,F,C,Q)@(B,F,Q,P) -> sum over refs -> (B,C,P)
+    d_r = np.matmul(a_hat[:, None], g).astype(F32)                            # (B,1,C,P)@(B,F,P,Q) -> (B,F,C,Q)
     g_xt = _normalise_bwd(t, n_t, d_a) * vt
     g_xr = _normalise_bwd(r, n_r, d_r) * vr
     return g_xt.reshape(b, c, h, w).astype(F32), g_xr.transpose(0, 2, 1, 3).reshape(b, c, f, h, w).astype(F32)
