@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must be loaded before the library: shares its libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtcl_hip.so")
+LIB_PATH = os.environ.get("TCL_LIB_PATH") or os.path.join(_HERE, "csrc", "libtcl_hip.so")  # override: A/B experiments only
 
 _c = ctypes
 _P, _I64, _INT, _SZ = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t

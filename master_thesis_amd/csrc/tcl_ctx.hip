@@ -148,16 +148,28 @@ struct CtxWs {
   float *gs;       // (B,R)    similarity after normalisation / zeroing
   float *dscale;   // (B,R)    d gs / d raw sum  (0 where v_sum was zero)
   float *partial;  // (B,R,nblk) per-block partial sums of the raw similarity
-  int nblk;
+  int nblk, csplit;
   size_t bytes;
 };
-constexpr int SIM_ITEMS = 4;  // (c,x) elements per thread in the similarity pass
+constexpr int CTX_PXW = 64;  // lanes along the pixel axis; each lane owns PX (1 or 2) adjacent pixels
+constexpr int CTX_RC = 8;    // reference frames accumulated per pass over the channels
+
+static int ctx_px(int64_t hw) { return hw % 2 == 0 ? 2 : 1; }
+static int ctx_xblocks(int64_t hw) { return (int)cdiv(hw, CTX_PXW * ctx_px(hw)); }
+static int ctx_csplit(int64_t B, int64_t C, int64_t hw) {
+  // enough blocks to fill the chip (>= ~8 per CU) without making each block's channel share trivial
+  int64_t want = cdiv((int64_t)kNumCU * 8, B * ctx_xblocks(hw));
+  int64_t maxs = cdiv(C, 4 * 4);  // at least 4 channels per wave
+  if (want > maxs) want = maxs;
+  return (int)(want < 1 ? 1 : want);
+}
 
 static CtxWs ctx_ws(void *base, int64_t B, int64_t C, int64_t R, int64_t hw) {
   CtxWs w;
   size_t off = 0;
   auto take = [&](size_t n) { float *p = (float *)((char *)base + off); off += round_up(n * sizeof(float), 256); return p; };
-  w.nblk = (int)cdiv(C * hw, 256 * SIM_ITEMS);
+  w.csplit = ctx_csplit(B, C, hw);
+  w.nblk = ctx_xblocks(hw) * w.csplit;
   w.vt = take((size_t)B * hw);
   w.vr = take((size_t)B * R * hw);
   w.gs = take((size_t)B * R);
@@ -167,40 +179,73 @@ static CtxWs ctx_ws(void *base, int64_t B, int64_t C, int64_t R, int64_t hw) {
   return w;
 }
 
-// grid (nblk, B).  partial[b][r][blk] = sum over the block's (c,x) elements of vt*vr_r*f_t*f_r.
+template <int PX> struct PxVec;
+template <> struct PxVec<1> { typedef float T; };
+template <> struct PxVec<2> { typedef float2 T; };
+template <int PX> __device__ __forceinline__ void ldpx(const float *p, float (&v)[PX]) {
+  if (PX == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[PX - 1] = t.y; }
+  else v[0] = p[0];
+}
+template <int PX> __device__ __forceinline__ void stpx(float *p, const float (&v)[PX]) {
+  if (PX == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[PX - 1]);
+  else p[0] = v[0];
+}
+
+// grid (xblocks, csplit, B), block (64,4): lane = PX adjacent pixels, wave = a strided subset of the channels.
+// partial[b][r][blk] = sum over the block's (c,x) of vt*vr_r*f_t*f_r; the mask is factored out of the channel sum.
+template <int PX>
 __global__ void __launch_bounds__(256) ctx_sim_kernel(const float *__restrict__ cf, const float *__restrict__ vt,
                                                       const float *__restrict__ vr, float *__restrict__ partial, int C, int R,
-                                                      int hw, int nblk) {
-  const int b = blockIdx.y;
-  const int64_t n_el = (int64_t)C * hw;
-  const float *cfb = cf + (int64_t)b * C * (R + 1) * hw;
-  const float *vtb = vt + (int64_t)b * hw, *vrb = vr + (int64_t)b * R * hw;
-  float ft[SIM_ITEMS];
-  int64_t off[SIM_ITEMS];
-  int xs[SIM_ITEMS];
+                                                      int hw, int nblk, unsigned xblocks, unsigned csplit) {
+  // 1-D grid, XCD-contiguous (x fastest, then channel split, then target): x-neighbours share cache lines
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned bxi = lin % xblocks, rest = lin / xblocks, cs = rest % csplit;
+  const int b = rest / csplit, lane = threadIdx.x, wv = threadIdx.y;
+  const int x = (bxi * CTX_PXW + lane) * PX;
+  const bool ok = x < hw;
+  const int cstep = 4 * csplit, c0 = cs * 4 + wv;
+  const float *cfb = cf + (int64_t)b * C * (R + 1) * hw + x;
+  __shared__ float red[4][CTX_RC];
+  float vtx[PX];
 #pragma unroll
-  for (int k = 0; k < SIM_ITEMS; ++k) {
-    const int64_t e = ((int64_t)blockIdx.x * SIM_ITEMS + k) * 256 + threadIdx.x;
-    if (e < n_el) {
-      const int c = (int)(e / hw), x = (int)(e - (int64_t)c * hw);
-      off[k] = (int64_t)c * (R + 1) * hw + x;
-      xs[k] = x;
-      ft[k] = cfb[off[k]] * vtb[x];
-    } else {
-      off[k] = -1; xs[k] = 0; ft[k] = 0.f;
+  for (int k = 0; k < PX; ++k) vtx[k] = 0.f;
+  if (ok) ldpx<PX>(vt + (int64_t)b * hw + x, vtx);
+  for (int r0 = 0; r0 < R; r0 += CTX_RC) {
+    float acc[CTX_RC][PX];
+#pragma unroll
+    for (int k = 0; k < CTX_RC; ++k)
+#pragma unroll
+      for (int e = 0; e < PX; ++e) acc[k][e] = 0.f;
+    if (ok)
+      for (int c = c0; c < C; c += cstep) {
+        const float *fp = cfb + (int64_t)c * (R + 1) * hw;
+        float ft[PX];
+        ldpx<PX>(fp, ft);
+#pragma unroll
+        for (int k = 0; k < CTX_RC; ++k)
+          if (r0 + k < R) {
+            float fr[PX];
+            ldpx<PX>(fp + (int64_t)(r0 + k + 1) * hw, fr);
+#pragma unroll
+            for (int e = 0; e < PX; ++e) acc[k][e] += ft[e] * fr[e];
+          }
+      }
+#pragma unroll
+    for (int k = 0; k < CTX_RC; ++k) {
+      float s = 0.f;
+      if (ok && r0 + k < R) {
+        float m[PX];
+        ldpx<PX>(vr + ((int64_t)b * R + r0 + k) * hw + x, m);
+#pragma unroll
+        for (int e = 0; e < PX; ++e) s += acc[k][e] * (vtx[e] * m[e]);
+      }
+      s = wave_sum(s);
+      if (lane == 0) red[wv][k] = s;
     }
-  }
-  __shared__ float red[4];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int r = 0; r < R; ++r) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < SIM_ITEMS; ++k)
-      if (off[k] >= 0) s += ft[k] * vrb[(int64_t)r * hw + xs[k]] * cfb[off[k] + (int64_t)(r + 1) * hw];
-    s = wave_sum(s);
-    if (lane == 0) red[wid] = s;
     __syncthreads();
-    if (threadIdx.x == 0) partial[((int64_t)b * R + r) * nblk + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (wv == 0 && lane < CTX_RC && r0 + lane < R)
+      partial[((int64_t)b * R + r0 + lane) * nblk + cs * xblocks + bxi] =
+          (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     __syncthreads();
   }
 }
@@ -237,21 +282,24 @@ __global__ void __launch_bounds__(256) ctx_finalize_kernel(const float *__restri
   }
 }
 
-// block = 64 pixels x 4 channel groups; dynamic LDS = R*64 floats (softmax weights of the block's pixels).
-// grid (ceil(hw/64), B).
+// grid (xblocks, B), block (64,4); dynamic LDS = R*64*PX floats (softmax weights of the block's pixels).
+template <int PX>
 __global__ void __launch_bounds__(256) ctx_aggregate_kernel(const float *__restrict__ cf, const float *__restrict__ vt,
                                                             const float *__restrict__ vr, const float *__restrict__ gs,
                                                             float *__restrict__ p_in, float *__restrict__ c_mask,
-                                                            float *__restrict__ c_match, int C, int R, int hw, int variant) {
-  extern __shared__ __attribute__((aligned(16))) float wts[];  // [R][64]
-  const int b = blockIdx.y, px = threadIdx.x & 63, cg = threadIdx.x >> 6;
-  const int x = blockIdx.x * 64 + px;
-  const bool ok = x < hw;
+                                                            float *__restrict__ c_match, int C, int R, int hw, int variant,
+                                                            unsigned xblocks) {
+  extern __shared__ __attribute__((aligned(16))) float wts[];  // [R][64*PX]
+  constexpr int NPX = CTX_PXW * PX;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = lin / xblocks, lane = threadIdx.x, wv = threadIdx.y, tid = wv * 64 + lane;
+  const int xb = (lin % xblocks) * NPX;
   const float *vrb = vr + (int64_t)b * R * hw;
-  const float vtx = ok ? vt[(int64_t)b * hw + x] : 0.f;
-  if (cg == 0) {
-    float cm = 0.f;
-    if (ok) {
+  // phase 1: one thread per pixel of the block computes that pixel's softmax over the references
+  if (tid < NPX) {
+    const int x = xb + tid;
+    if (x < hw) {
+      const float vtx = vt[(int64_t)b * hw + x];
       const float *g = gs + (int64_t)b * R;
       float mx = -INFINITY;
       for (int r = 0; r < R; ++r) mx = fmaxf(mx, g[r] * vrb[(int64_t)r * hw + x]);
@@ -262,10 +310,11 @@ __global__ void __launch_bounds__(256) ctx_aggregate_kernel(const float *__restr
       }
       if (s < 1e-4f) s += 1.f;
       const float hole = variant == TCL_CTX_COMPLETE ? 1.f - vtx : 1.f;
+      float cm = 0.f;
       for (int r = 0; r < R; ++r) {
         const float m = vrb[(int64_t)r * hw + x];
         const float wgt = (expf(g[r] * m - mx) * m / s) * hole;
-        wts[r * 64 + px] = wgt;
+        wts[r * NPX + tid] = wgt;
         c_match[((int64_t)b * R + r) * hw + x] = wgt;
         cm += wgt * m;
       }
@@ -274,28 +323,38 @@ __global__ void __launch_bounds__(256) ctx_aggregate_kernel(const float *__restr
       const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
       p_in[((int64_t)b * (cch + 1) + cch) * hw + x] = cm;
     } else {
-      for (int r = 0; r < R; ++r) wts[r * 64 + px] = 0.f;
+      for (int r = 0; r < R; ++r) wts[r * NPX + tid] = 0.f;
     }
   }
   __syncthreads();
-  if (!ok) return;
+  // phase 2: lane = PX pixels, wave = channels wv, wv+4, ...
+  const int x = xb + lane * PX;
+  if (x >= hw) return;
+  float vtx[PX];
+  ldpx<PX>(vt + (int64_t)b * hw + x, vtx);
   const float *cfb = cf + (int64_t)b * C * (R + 1) * hw + x;
-  if (variant == TCL_CTX_COMPLETE) {
-    float *o = p_in + (int64_t)b * (C + 1) * hw + x;
-    for (int c = cg; c < C; c += 4) {
-      const float *fp = cfb + (int64_t)c * (R + 1) * hw;
-      float acc = 0.f;
-      for (int r = 0; r < R; ++r) acc += fp[(int64_t)(r + 1) * hw] * wts[r * 64 + px];
-      o[(int64_t)c * hw] = fp[0] * vtx + acc;
+  const bool complete = variant == TCL_CTX_COMPLETE;
+  float *o = p_in + (int64_t)b * ((complete ? C : 2 * C) + 1) * hw + x;
+  for (int c = wv; c < C; c += 4) {
+    const float *fp = cfb + (int64_t)c * (R + 1) * hw;
+    float acc[PX], ft[PX];
+#pragma unroll
+    for (int e = 0; e < PX; ++e) acc[e] = 0.f;
+    ldpx<PX>(fp, ft);
+    for (int r = 0; r < R; ++r) {
+      float fr[PX], wg[PX];
+      ldpx<PX>(fp + (int64_t)(r + 1) * hw, fr);
+      ldpx<PX>(wts + r * NPX + lane * PX, wg);
+#pragma unroll
+      for (int e = 0; e < PX; ++e) acc[e] += fr[e] * wg[e];
     }
-  } else {
-    float *o = p_in + (int64_t)b * (2 * C + 1) * hw + x;
-    for (int c = cg; c < C; c += 4) {
-      const float *fp = cfb + (int64_t)c * (R + 1) * hw;
-      float acc = 0.f;
-      for (int r = 0; r < R; ++r) acc += fp[(int64_t)(r + 1) * hw] * wts[r * 64 + px];
-      o[(int64_t)c * hw] = fp[0];
-      o[(int64_t)(C + c) * hw] = acc;
+    if (complete) {
+#pragma unroll
+      for (int e = 0; e < PX; ++e) acc[e] = ft[e] * vtx[e] + acc[e];
+      stpx<PX>(o + (int64_t)c * hw, acc);
+    } else {
+      stpx<PX>(o + (int64_t)c * hw, ft);
+      stpx<PX>(o + (int64_t)(C + c) * hw, acc);
     }
   }
 }
@@ -316,11 +375,21 @@ __global__ void __launch_bounds__(256) ctx_bwd_match_kernel(const float *__restr
   const int out_off = variant == TCL_CTX_COMPLETE ? 0 : C;   // channel offset of g_out inside g_p_in
   const float *gpb = g_p_in + (int64_t)b * (cch + 1) * hw + x;
   const float *cfb = cf + (int64_t)b * C * (R + 1) * hw + x;
-  for (int r = 0; r < R; ++r) {
-    float acc = 0.f;
+  for (int r0 = 0; r0 < R; r0 += CTX_RC) {
+    float acc[CTX_RC];
+#pragma unroll
+    for (int k = 0; k < CTX_RC; ++k) acc[k] = 0.f;
     if (ok)
-      for (int c = cg; c < C; c += 4) acc += gpb[(int64_t)(out_off + c) * hw] * cfb[((int64_t)c * (R + 1) + r + 1) * hw];
-    dm[(cg * R + r) * 64 + px] = acc;
+      for (int c = cg; c < C; c += 4) {
+        const float g = gpb[(int64_t)(out_off + c) * hw];
+        const float *fp = cfb + (int64_t)c * (R + 1) * hw;
+#pragma unroll
+        for (int k = 0; k < CTX_RC; ++k)
+          if (r0 + k < R) acc[k] += g * fp[(int64_t)(r0 + k + 1) * hw];
+      }
+#pragma unroll
+    for (int k = 0; k < CTX_RC; ++k)
+      if (r0 + k < R) dm[(cg * R + r0 + k) * 64 + px] = acc[k];
   }
   __syncthreads();
   if (cg != 0) return;
@@ -379,35 +448,46 @@ __global__ void __launch_bounds__(256) ctx_bwd_finalize_kernel(const float *__re
   if (lane == 0) coef[br] = s * dscale[br];
 }
 
-// Pass 2: thread per (c,x) of target b; writes all R+1 frames of g_c_feats.  grid (ceil(C*hw/256), B).
+// Pass 2: grid (xblocks, ceil(C/4), B), block (64,4): lane = PX pixels, threadIdx.y = channel; writes all R+1 frames.
+template <int PX>
 __global__ void __launch_bounds__(256) ctx_bwd_feats_kernel(const float *__restrict__ g_p_in, const float *__restrict__ cf,
                                                             const float *__restrict__ c_match, const float *__restrict__ vt,
                                                             const float *__restrict__ vr, const float *__restrict__ coef,
-                                                            float *__restrict__ g_cf, int C, int R, int hw, int variant) {
-  const int b = blockIdx.y;
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)C * hw) return;
-  const int c = (int)(e / hw), x = (int)(e - (int64_t)c * hw);
+                                                            float *__restrict__ g_cf, int C, int R, int hw, int variant, unsigned xblocks) {
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x), cgroups = (C + 3) / 4;
+  const unsigned bxi = lin % xblocks, rest = lin / xblocks;
+  const int b = rest / cgroups, c = (rest % cgroups) * 4 + threadIdx.y;
+  const int x = (bxi * CTX_PXW + threadIdx.x) * PX;
+  if (x >= hw || c >= C) return;
   const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
   const float *gpb = g_p_in + (int64_t)b * (cch + 1) * hw + x;
-  const float vtx = vt[(int64_t)b * hw + x];
-  float g_ft, g_out;
+  float vtx[PX], g_ft[PX], g_out[PX], ft[PX];
+  ldpx<PX>(vt + (int64_t)b * hw + x, vtx);
   if (variant == TCL_CTX_COMPLETE) {
-    g_out = gpb[(int64_t)c * hw];
-    g_ft = g_out * vtx;
+    ldpx<PX>(gpb + (int64_t)c * hw, g_out);
+#pragma unroll
+    for (int e = 0; e < PX; ++e) g_ft[e] = g_out[e] * vtx[e];
   } else {
-    g_ft = gpb[(int64_t)c * hw];
-    g_out = gpb[(int64_t)(C + c) * hw];
+    ldpx<PX>(gpb + (int64_t)c * hw, g_ft);
+    ldpx<PX>(gpb + (int64_t)(C + c) * hw, g_out);
   }
   const int64_t base = ((int64_t)b * C + c) * (R + 1) * hw + x;
-  const float ft = cf[base];
+  ldpx<PX>(cf + base, ft);
   for (int r = 0; r < R; ++r) {
-    const float k = coef[b * R + r] * (vtx * vr[((int64_t)b * R + r) * hw + x]);
-    const float fr = cf[base + (int64_t)(r + 1) * hw];
-    g_ft += k * fr;
-    g_cf[base + (int64_t)(r + 1) * hw] = g_out * c_match[((int64_t)b * R + r) * hw + x] + k * ft;
+    float m[PX], fr[PX], cm[PX], o[PX];
+    ldpx<PX>(vr + ((int64_t)b * R + r) * hw + x, m);
+    ldpx<PX>(cf + base + (int64_t)(r + 1) * hw, fr);
+    ldpx<PX>(c_match + ((int64_t)b * R + r) * hw + x, cm);
+    const float cr = coef[b * R + r];
+#pragma unroll
+    for (int e = 0; e < PX; ++e) {
+      const float k = cr * (vtx[e] * m[e]);
+      g_ft[e] += k * fr[e];
+      o[e] = g_out[e] * cm[e] + k * ft[e];
+    }
+    stpx<PX>(g_cf + base + (int64_t)(r + 1) * hw, o);
   }
-  g_cf[base] = g_ft;
+  stpx<PX>(g_cf + base, g_ft);
 }
 
 static unsigned stream_blocks(int64_t total) {
@@ -486,11 +566,19 @@ extern "C" int tcl_ctx_fwd(const float *c_feats, const float *v_t, const float *
   const CtxWs ws = ctx_ws(workspace, B, C, R, hw);
   hipLaunchKernelGGL(resize_mask_kernel, dim3(stream_blocks(B * hw)), dim3(256), 0, s, v_t, ws.vt, B, (int)H, (int)W, (int)h, (int)w);
   hipLaunchKernelGGL(resize_mask_kernel, dim3(stream_blocks(B * R * hw)), dim3(256), 0, s, v_aligned, ws.vr, B * R, (int)H, (int)W, (int)h, (int)w);
-  hipLaunchKernelGGL(ctx_sim_kernel, dim3(ws.nblk, (unsigned)B), dim3(256), 0, s, c_feats, ws.vt, ws.vr, ws.partial, (int)C, (int)R, hw, ws.nblk);
+  const int px = ctx_px(hw), xb = ctx_xblocks(hw);
+  if (px == 2)
+    hipLaunchKernelGGL(ctx_sim_kernel<2>, dim3((unsigned)(xb * ws.csplit * B)), dim3(64, 4), 0, s, c_feats, ws.vt, ws.vr, ws.partial, (int)C, (int)R, hw, ws.nblk, (unsigned)xb, (unsigned)ws.csplit);
+  else
+    hipLaunchKernelGGL(ctx_sim_kernel<1>, dim3((unsigned)(xb * ws.csplit * B)), dim3(64, 4), 0, s, c_feats, ws.vt, ws.vr, ws.partial, (int)C, (int)R, hw, ws.nblk, (unsigned)xb, (unsigned)ws.csplit);
   hipLaunchKernelGGL(ctx_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, ws.vt, ws.vr, ws.partial, ws.gs, ws.dscale,
                      (int)(B * R), (int)R, (int)C, hw, ws.nblk, variant, normalize);
-  hipLaunchKernelGGL(ctx_aggregate_kernel, dim3((unsigned)cdiv(hw, 64), (unsigned)B), dim3(256), (size_t)R * 64 * sizeof(float), s, c_feats,
-                     ws.vt, ws.vr, ws.gs, p_in, c_mask, c_match, (int)C, (int)R, hw, variant);
+  if (px == 2)
+    hipLaunchKernelGGL(ctx_aggregate_kernel<2>, dim3((unsigned)(xb * B)), dim3(64, 4), (size_t)R * 128 * sizeof(float), s, c_feats,
+                       ws.vt, ws.vr, ws.gs, p_in, c_mask, c_match, (int)C, (int)R, hw, variant, (unsigned)xb);
+  else
+    hipLaunchKernelGGL(ctx_aggregate_kernel<1>, dim3((unsigned)(xb * B)), dim3(64, 4), (size_t)R * 64 * sizeof(float), s, c_feats,
+                       ws.vt, ws.vr, ws.gs, p_in, c_mask, c_match, (int)C, (int)R, hw, variant, (unsigned)xb);
   return check_launch("tcl_ctx_fwd");
 }
 
@@ -519,7 +607,11 @@ extern "C" int tcl_ctx_bwd(const float *g_p_in, const float *g_c_mask, const flo
   hipLaunchKernelGGL(ctx_bwd_match_kernel, dim3(nbx, (unsigned)B), dim3(256), (size_t)4 * R * 64 * sizeof(float), s, g_p_in, g_c_mask, c_feats,
                      ws.vt, ws.vr, ws.gs, partial, (int)C, (int)R, hw, variant, nbx);
   hipLaunchKernelGGL(ctx_bwd_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, partial, ws.dscale, coef, (int)(B * R), nbx);
-  hipLaunchKernelGGL(ctx_bwd_feats_kernel, dim3((unsigned)cdiv(C * hw, 256), (unsigned)B), dim3(256), 0, s, g_p_in, c_feats, c_match, ws.vt,
-                     ws.vr, coef, g_c_feats, (int)C, (int)R, hw, variant);
+  if (ctx_px(hw) == 2)
+    hipLaunchKernelGGL(ctx_bwd_feats_kernel<2>, dim3((unsigned)(ctx_xblocks(hw) * cdiv(C, 4) * B)), dim3(64, 4), 0, s, g_p_in, c_feats,
+                       c_match, ws.vt, ws.vr, coef, g_c_feats, (int)C, (int)R, hw, variant, (unsigned)ctx_xblocks(hw));
+  else
+    hipLaunchKernelGGL(ctx_bwd_feats_kernel<1>, dim3((unsigned)(ctx_xblocks(hw) * cdiv(C, 4) * B)), dim3(64, 4), 0, s, g_p_in, c_feats,
+                       c_match, ws.vt, ws.vr, coef, g_c_feats, (int)C, (int)R, hw, variant, (unsigned)ctx_xblocks(hw));
   return check_launch("tcl_ctx_bwd");
 }

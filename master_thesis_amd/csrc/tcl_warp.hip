@@ -20,6 +20,8 @@ struct WarpArgs {
   float *vo; int64_t vo_sb, vo_sf;
   int NB, NF, C, H, W;
   int align_corners, v_mode;
+  float stepx, stepy;  // 2/(W-1), 2/(H-1) (torch.linspace step), divided on the host
+  unsigned tiles_x, tiles_y;
 };
 
 __device__ __forceinline__ float unnormalise(float g, int size, bool align_corners) {
@@ -28,10 +30,11 @@ __device__ __forceinline__ float unnormalise(float g, int size, bool align_corne
 }
 
 struct Taps {
-  float nw, ne, sw, se;      // weights
-  float wx, ex, ny, sy;      // distances
-  int o_nw, o_ne, o_sw, o_se;  // plane offsets (valid only where the flag is set)
-  bool b_nw, b_ne, b_sw, b_se;
+  float nw, ne, sw, se;  // weights
+  float wx, ex, ny, sy;  // distances
+  int xi, yi;            // integer corner (valid where a flag is set)
+  int xa, ya, yb;        // clamped column of the 2-wide load and clamped north / south rows: always inside the image
+  bool xw, xe, yn, ys;   // west / east column and north / south row inside the image
 };
 
 __device__ __forceinline__ Taps make_taps(float ix, float iy, int H, int W) {
@@ -46,30 +49,71 @@ __device__ __forceinline__ Taps make_taps(float ix, float iy, int H, int W) {
   t.sw = __fmul_rn(t.ny, t.ex);
   t.se = __fmul_rn(t.ny, t.wx);
   // bounds in the float domain (NaN / huge coordinates are simply out of bounds)
-  const bool xw = (x0 >= 0.f) && (x0 <= (float)(W - 1));
-  const bool xe = (x0 >= -1.f) && (x0 <= (float)(W - 2));
-  const bool yn = (y0 >= 0.f) && (y0 <= (float)(H - 1));
-  const bool ys = (y0 >= -1.f) && (y0 <= (float)(H - 2));
-  const int xi = (xw || xe) ? (int)x0 : 0, yi = (yn || ys) ? (int)y0 : 0;
-  t.b_nw = xw && yn; t.b_ne = xe && yn; t.b_sw = xw && ys; t.b_se = xe && ys;
-  t.o_nw = yi * W + xi; t.o_ne = t.o_nw + 1; t.o_sw = t.o_nw + W; t.o_se = t.o_sw + 1;
+  t.xw = (x0 >= 0.f) && (x0 <= (float)(W - 1));
+  t.xe = (x0 >= -1.f) && (x0 <= (float)(W - 2));
+  t.yn = (y0 >= 0.f) && (y0 <= (float)(H - 1));
+  t.ys = (y0 >= -1.f) && (y0 <= (float)(H - 2));
+  t.xi = (t.xw || t.xe) ? (int)x0 : 0;
+  t.yi = (t.yn || t.ys) ? (int)y0 : 0;
+  t.xa = max(0, min(t.xi, W - 2));
+  t.ya = max(0, min(t.yi, H - 1));
+  t.yb = max(0, min(t.yi + 1, H - 1));
   return t;
 }
 
-__device__ __forceinline__ float bilinear(const float *plane, const Taps &t) {
-  const float a = t.b_nw ? plane[t.o_nw] : 0.f, b = t.b_ne ? plane[t.o_ne] : 0.f;
-  const float c = t.b_sw ? plane[t.o_sw] : 0.f, d = t.b_se ? plane[t.o_se] : 0.f;
+// The west/east neighbours of one image row with ONE unconditional 8-byte load at the clamped column (planes are only
+// 4-byte aligned), then selects: straight-line code, so all taps of all channels are in flight together.  W2 = (W >= 2).
+struct __attribute__((packed, aligned(4))) F2U { float a, b; };
+struct TapVals { F2U n, s; };
+
+template <bool W2>
+__device__ __forceinline__ TapVals fetch_taps(const float *plane, const Taps &t, int W) {
+  TapVals v;
+  if (W2) {
+    v.n = *reinterpret_cast<const F2U *>(plane + t.ya * W + t.xa);
+    v.s = *reinterpret_cast<const F2U *>(plane + t.yb * W + t.xa);
+  } else {  // one-pixel-wide image
+    v.n.a = plane[t.ya * W]; v.n.b = 0.f;
+    v.s.a = plane[t.yb * W]; v.s.b = 0.f;
+  }
+  return v;
+}
+
+template <bool W2>
+__device__ __forceinline__ void select_taps(const TapVals &v, const Taps &t, float &a, float &b, float &c, float &d) {
+  const bool same = !W2 || t.xi == t.xa;   // false only at xi = -1 (east = .a) and xi = W-1 (west = .b)
+  a = (t.yn && t.xw) ? (same ? v.n.a : v.n.b) : 0.f;
+  b = (t.yn && t.xe) ? (same ? v.n.b : v.n.a) : 0.f;
+  c = (t.ys && t.xw) ? (same ? v.s.a : v.s.b) : 0.f;
+  d = (t.ys && t.xe) ? (same ? v.s.b : v.s.a) : 0.f;
+}
+
+__device__ __forceinline__ float blend(float a, float b, float c, float d, const Taps &t) {
   return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a, t.nw), __fmul_rn(b, t.ne)), __fmul_rn(c, t.sw)), __fmul_rn(d, t.se));
+}
+
+template <bool W2>
+__device__ __forceinline__ void load_taps(const float *plane, const Taps &t, int W, float &a, float &b, float &c, float &d) {
+  const TapVals v = fetch_taps<W2>(plane, t, W);
+  select_taps<W2>(v, t, a, b, c, d);
+}
+
+// torch.linspace(-1,1,n)[i] with the step precomputed on the host (same IEEE division), see base_coord()
+__device__ __forceinline__ float base_coord_step(int i, int n, float step, bool align_corners) {
+  if (n <= 1) return 0.f;
+  float r = (i < n / 2) ? __fadd_rn(-1.f, __fmul_rn(step, (float)i)) : __fsub_rn(1.f, __fmul_rn(step, (float)(n - 1 - i)));
+  if (!align_corners) r = __fdiv_rn(__fmul_rn(r, (float)(n - 1)), (float)n);
+  return r;
 }
 
 template <bool HAS_THETA>
 __device__ __forceinline__ void sample_pos(const float *grid, const float *theta, int n, int y, int x, int H, int W,
-                                           bool ac, float &ix, float &iy, float &xs, float &ys) {
+                                           float stepx, float stepy, bool ac, float &ix, float &iy, float &xs, float &ys) {
   float gx, gy;
   if (HAS_THETA) {
     const float *th = theta + (int64_t)n * 6;
-    xs = base_coord(x, W, ac);
-    ys = base_coord(y, H, ac);
+    xs = base_coord_step(x, W, stepx, ac);
+    ys = base_coord_step(y, H, stepy, ac);
     gx = __fadd_rn(__fadd_rn(__fmul_rn(th[0], xs), __fmul_rn(th[1], ys)), th[2]);
     gy = __fadd_rn(__fadd_rn(__fmul_rn(th[3], xs), __fmul_rn(th[4], ys)), th[5]);
   } else {
@@ -80,34 +124,81 @@ __device__ __forceinline__ void sample_pos(const float *grid, const float *theta
   iy = unnormalise(gy, H, ac);
 }
 
-template <bool HAS_THETA>
+#ifndef TCL_TILE_W
+#define TCL_TILE_W 64
+#endif
+constexpr int TILE_W = TCL_TILE_W, TILE_H = 256 / TCL_TILE_W;  // 256 threads per block; a wave covers 64 consecutive pixels of one row
+constexpr int FWD_PPT = 2;              // rows per lane in the forward kernel
+constexpr int FWD_MAXC = 3;             // channels whose taps are fetched together (straight-line loads)
+
+// grid (ceil(W/64), ceil(H/(4*PPT)), NB*NF), block (64,4); lane (tx,ty) owns rows by*4*PPT + ty + 4k.
+// Phases: positions -> ALL tap loads (unconditional, clamped addresses) -> selects + blend -> predicated stores.
+template <bool HAS_THETA, bool W2>
 __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
-  const int HW = a.H * a.W;
-  const int64_t total = (int64_t)a.NB * a.NF * HW;
+  // 1-D grid, XCD-contiguous: tiles that share source cache lines (neighbours in x / y, same image) run on one XCD's L2
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned bx = lin % a.tiles_x, rest = lin / a.tiles_x, by = rest % a.tiles_y;
+  const int n = rest / a.tiles_y, b = n / a.NF, f = n - b * a.NF;
+  const int x = bx * TILE_W + threadIdx.x;
+  if (x >= a.W) return;
+  const int ybase = by * (TILE_H * FWD_PPT) + threadIdx.y;
   const bool ac = a.align_corners != 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int n = (int)(i / HW), pix = (int)(i - (int64_t)n * HW);
-    const int y = pix / a.W, x = pix - y * a.W;
-    const int b = n / a.NF, f = n - b * a.NF;
-    float ix, iy, xs, ys;
-    sample_pos<HAS_THETA>(a.grid, a.theta, n, y, x, a.H, a.W, ac, ix, iy, xs, ys);
-    const Taps t = make_taps(ix, iy, a.H, a.W);
-    if (a.xo) {
-      const float *xp = a.x + b * a.x_sb + f * a.x_sf;
-      float *op = a.xo + b * a.xo_sb + f * a.xo_sf + pix;
-      for (int c = 0; c < a.C; ++c) op[c * a.xo_sc] = bilinear(xp + c * a.x_sc, t);
+  Taps t[FWD_PPT];
+  float ixs[FWD_PPT], iys[FWD_PPT];
+#pragma unroll
+  for (int k = 0; k < FWD_PPT; ++k) {
+    const int y = min(ybase + k * TILE_H, a.H - 1);   // rows past the image recompute the last row; their stores are skipped
+    float xs, ys;
+    sample_pos<HAS_THETA>(a.grid, a.theta, n, y, x, a.H, a.W, a.stepx, a.stepy, ac, ixs[k], iys[k], xs, ys);
+    t[k] = make_taps(ixs[k], iys[k], a.H, a.W);
+  }
+  const float *vp = a.v + b * a.v_sb + f * a.v_sf;
+  float vr[FWD_PPT];
+  if (a.v_mode == TCL_VMODE_NEAREST) {
+#pragma unroll
+    for (int k = 0; k < FWD_PPT; ++k) {
+      const float xn = rintf(ixs[k]), yn = rintf(iys[k]);  // v_rndne: half to even, as std::nearbyint
+      const bool inb = (xn >= 0.f) && (xn <= (float)(a.W - 1)) && (yn >= 0.f) && (yn <= (float)(a.H - 1));
+      const float val = vp[(inb ? (int)yn : 0) * a.W + (inb ? (int)xn : 0)];   // unconditional load, then select
+      vr[k] = inb ? val : 0.f;
     }
-    if (a.v_mode != TCL_VMODE_NONE) {
-      const float *vp = a.v + b * a.v_sb + f * a.v_sf;
-      float r;
-      if (a.v_mode == TCL_VMODE_NEAREST) {
-        const float xn = rintf(ix), yn = rintf(iy);  // v_rndne: half to even, as std::nearbyint
-        const bool inb = (xn >= 0.f) && (xn <= (float)(a.W - 1)) && (yn >= 0.f) && (yn <= (float)(a.H - 1));
-        r = inb ? vp[(int)yn * a.W + (int)xn] : 0.f;
-      } else {
-        r = bilinear(vp, t) > 0.5f ? 1.f : 0.f;
+  } else if (a.v_mode == TCL_VMODE_BILINEAR_THRESHOLD) {
+#pragma unroll
+    for (int k = 0; k < FWD_PPT; ++k) {
+      float p, q, r, s;
+      load_taps<W2>(vp, t[k], a.W, p, q, r, s);
+      vr[k] = blend(p, q, r, s, t[k]) > 0.5f ? 1.f : 0.f;
+    }
+  }
+  if (a.xo) {
+    const float *xp = a.x + b * a.x_sb + f * a.x_sf;
+    float *op = a.xo + b * a.xo_sb + f * a.xo_sf + x;
+    for (int c0 = 0; c0 < a.C; c0 += FWD_MAXC) {
+      TapVals tv[FWD_MAXC][FWD_PPT];
+#pragma unroll
+      for (int c = 0; c < FWD_MAXC; ++c) {
+        const float *plane = xp + min(c0 + c, a.C - 1) * a.x_sc;
+#pragma unroll
+        for (int k = 0; k < FWD_PPT; ++k) tv[c][k] = fetch_taps<W2>(plane, t[k], a.W);
       }
-      a.vo[b * a.vo_sb + f * a.vo_sf + pix] = r;
+#pragma unroll
+      for (int c = 0; c < FWD_MAXC; ++c)
+#pragma unroll
+        for (int k = 0; k < FWD_PPT; ++k) {
+          float p, q, r, s;
+          select_taps<W2>(tv[c][k], t[k], p, q, r, s);
+          const float val = blend(p, q, r, s, t[k]);
+          const int y = ybase + k * TILE_H;
+          if (c0 + c < a.C && y < a.H) op[(c0 + c) * a.xo_sc + y * a.W] = val;
+        }
+    }
+  }
+  if (a.v_mode != TCL_VMODE_NONE) {
+    float *vo = a.vo + b * a.vo_sb + f * a.vo_sf + x;
+#pragma unroll
+    for (int k = 0; k < FWD_PPT; ++k) {
+      const int y = ybase + k * TILE_H;
+      if (y < a.H) vo[y * a.W] = vr[k];
     }
   }
 }
@@ -121,63 +212,70 @@ struct WarpBwdArgs {
   float *partial;  // (N, blocks_per_image, 6) when theta
   int NB, NF, C, H, W;
   int align_corners;
+  float stepx, stepy;
+  unsigned tiles_x, tiles_y;
 };
 
-// grid = (blocks_per_image, NB*NF); every block owns a contiguous pixel range of one image.
+// grid (ceil(W/64), ceil(H/4), NB*NF), block (64,4)
 template <bool HAS_THETA>
 __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
-  const int HW = a.H * a.W;
-  const int n = blockIdx.y;
-  const int b = n / a.NF, f = n - b * a.NF;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned bx = lin % a.tiles_x, rest = lin / a.tiles_x, by = rest % a.tiles_y;
+  const int n = rest / a.tiles_y, b = n / a.NF, f = n - b * a.NF;
+  const int x = bx * TILE_W + threadIdx.x, y = by * TILE_H + threadIdx.y;
+  const bool ok = x < a.W && y < a.H;
   const bool ac = a.align_corners != 0;
-  const float mx = ac ? 0.5f * (float)(a.W - 1) : 0.5f * (float)a.W;
-  const float my = ac ? 0.5f * (float)(a.H - 1) : 0.5f * (float)a.H;
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const float *xp = a.x + b * a.x_sb + f * a.x_sf;
-  const float *gp = a.go + b * a.go_sb + f * a.go_sf;
-  float *gxp = a.gx ? a.gx + b * a.gx_sb + f * a.gx_sf : nullptr;
-  for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < HW; pix += gridDim.x * blockDim.x) {
-    const int y = pix / a.W, x = pix - y * a.W;
+  if (ok) {
+    const int HW = a.H * a.W, pix = y * a.W + x;
+    const float mx = ac ? 0.5f * (float)(a.W - 1) : 0.5f * (float)a.W;
+    const float my = ac ? 0.5f * (float)(a.H - 1) : 0.5f * (float)a.H;
+    const float *xp = a.x + b * a.x_sb + f * a.x_sf;
+    const float *gp = a.go + b * a.go_sb + f * a.go_sf;
+    float *gxp = a.gx ? a.gx + b * a.gx_sb + f * a.gx_sf : nullptr;
     float ix, iy, xs, ys;
-    sample_pos<HAS_THETA>(a.grid, a.theta, n, y, x, a.H, a.W, ac, ix, iy, xs, ys);
+    sample_pos<HAS_THETA>(a.grid, a.theta, n, y, x, a.H, a.W, a.stepx, a.stepy, ac, ix, iy, xs, ys);
     const Taps t = make_taps(ix, iy, a.H, a.W);
+    const int o_nw = t.yi * a.W + t.xi;
     float gix = 0.f, giy = 0.f;
     for (int c = 0; c < a.C; ++c) {
       const float g = gp[c * a.go_sc + pix];
-      const float *plane = xp + c * a.x_sc;
-      const float vnw = t.b_nw ? plane[t.o_nw] : 0.f, vne = t.b_ne ? plane[t.o_ne] : 0.f;
-      const float vsw = t.b_sw ? plane[t.o_sw] : 0.f, vse = t.b_se ? plane[t.o_se] : 0.f;
+      float vnw, vne, vsw, vse;
+      if (a.W >= 2) load_taps<true>(xp + c * a.x_sc, t, a.W, vnw, vne, vsw, vse);
+      else load_taps<false>(xp + c * a.x_sc, t, a.W, vnw, vne, vsw, vse);
       gix += g * ((vne - vnw) * t.sy + (vse - vsw) * t.ny);
       giy += g * ((vsw - vnw) * t.ex + (vse - vne) * t.wx);
       if (gxp) {
-        float *gplane = gxp + c * a.gx_sc;
-        if (t.b_nw) atomicAdd(gplane + t.o_nw, g * t.nw);
-        if (t.b_ne) atomicAdd(gplane + t.o_ne, g * t.ne);
-        if (t.b_sw) atomicAdd(gplane + t.o_sw, g * t.sw);
-        if (t.b_se) atomicAdd(gplane + t.o_se, g * t.se);
+        float *gplane = gxp + c * a.gx_sc + o_nw;
+        if (t.xw && t.yn) atomicAdd(gplane, g * t.nw);
+        if (t.xe && t.yn) atomicAdd(gplane + 1, g * t.ne);
+        if (t.xw && t.ys) atomicAdd(gplane + a.W, g * t.sw);
+        if (t.xe && t.ys) atomicAdd(gplane + a.W + 1, g * t.se);
       }
     }
     gix *= mx;
     giy *= my;
     if (HAS_THETA) {
-      acc[0] += gix * xs; acc[1] += gix * ys; acc[2] += gix;
-      acc[3] += giy * xs; acc[4] += giy * ys; acc[5] += giy;
+      acc[0] = gix * xs; acc[1] = gix * ys; acc[2] = gix;
+      acc[3] = giy * xs; acc[4] = giy * ys; acc[5] = giy;
     } else if (a.g_grid) {
       reinterpret_cast<float2 *>(a.g_grid)[(int64_t)n * HW + pix] = make_float2(gix, giy);
     }
   }
   if (HAS_THETA && a.partial) {
     __shared__ float red[4][6];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int tid = threadIdx.y * TILE_W + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const float s = wave_sum(acc[k]);
-      if (lane == 0) red[wid][k] = s;
+      if ((tid & 63) == 0) red[tid >> 6][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 6) {
-      const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-      a.partial[((int64_t)n * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = s;
+    if (tid < 6) {
+      const int k = tid;
+      const float s = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+      const int64_t blk = (int64_t)by * a.tiles_x + bx, nblk = (int64_t)a.tiles_x * a.tiles_y;
+      a.partial[((int64_t)n * nblk + blk) * 6 + k] = s;
     }
   }
 }
@@ -200,13 +298,7 @@ __global__ void vmap_kernel(const float *va, const float *vt, float *out, int64_
   }
 }
 
-static int bwd_blocks_per_image(int64_t HW, int64_t N) {
-  int64_t per = cdiv(HW, 256);
-  const int64_t cap = cdiv((int64_t)kMaxStreamBlocks, N);  // keep the whole grid near 8 blocks per CU
-  if (per > cap) per = cap;
-  if (per < 1) per = 1;
-  return (int)per;
-}
+static inline float lin_step(int64_t n) { return n > 1 ? 2.f / (float)(n - 1) : 0.f; }
 
 }  // namespace tcl
 
@@ -224,23 +316,27 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
   TCL_REQUIRE((x_out == nullptr) || (x != nullptr && C > 0), TCL_ERR_ARG, "tcl_warp_fwd: x_out given without x");
   TCL_REQUIRE(x_out || v_mode != TCL_VMODE_NONE, TCL_ERR_ARG, "tcl_warp_fwd: nothing to compute");
   TCL_REQUIRE(!grid || aligned(grid, 8), TCL_ERR_ARG, "tcl_warp_fwd: grid must be 8-byte aligned");
-  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < (1LL << 30), TCL_ERR_SHAPE, "tcl_warp_fwd: image too large");
+  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536 && cdiv(H, TILE_H) < 65536, TCL_ERR_SHAPE, "tcl_warp_fwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   WarpArgs a{x, x_sb, x_sf, x_sc, v, v_sb, v_sf, grid, theta, x_out, xo_sb, xo_sf, xo_sc, v_out, vo_sb, vo_sf,
-             (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode};
-  const int64_t total = NB * NF * H * W;
-  int64_t blocks = cdiv(total, 256);
-  if (blocks > kMaxStreamBlocks * 4) blocks = kMaxStreamBlocks * 4;
+             (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H),
+             (unsigned)cdiv(W, TILE_W), (unsigned)cdiv(H, TILE_H * FWD_PPT)};
   hipStream_t s = (hipStream_t)stream;
-  if (theta)
-    hipLaunchKernelGGL(warp_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(warp_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * NB * NF;
+  TCL_REQUIRE(nblocks < (1LL << 31), TCL_ERR_SHAPE, "tcl_warp_fwd: grid too large");
+  const dim3 grd((unsigned)nblocks), blk(TILE_W, TILE_H);
+  if (theta) {
+    if (W >= 2) hipLaunchKernelGGL((warp_fwd_kernel<true, true>), grd, blk, 0, s, a);
+    else hipLaunchKernelGGL((warp_fwd_kernel<true, false>), grd, blk, 0, s, a);
+  } else {
+    if (W >= 2) hipLaunchKernelGGL((warp_fwd_kernel<false, true>), grd, blk, 0, s, a);
+    else hipLaunchKernelGGL((warp_fwd_kernel<false, false>), grd, blk, 0, s, a);
+  }
   return check_launch("tcl_warp_fwd");
 }
 
 extern "C" size_t tcl_warp_bwd_workspace_bytes(int64_t NB, int64_t NF, int64_t H, int64_t W, int have_theta) {
   if (!have_theta || NB <= 0 || NF <= 0 || H <= 0 || W <= 0) return 0;
-  return round_up((size_t)(NB * NF) * bwd_blocks_per_image(H * W, NB * NF) * 6 * sizeof(float), 256);
+  return round_up((size_t)(NB * NF) * cdiv(W, TILE_W) * cdiv(H, TILE_H) * 6 * sizeof(float), 256);
 }
 
 extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_sf, int64_t go_sc, const float *x,
@@ -254,10 +350,10 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
   TCL_REQUIRE(!(grid && g_theta) && !(theta && g_grid), TCL_ERR_ARG, "tcl_warp_bwd: gradient kind does not match the forward's source");
   TCL_REQUIRE(!grid || aligned(grid, 8), TCL_ERR_ARG, "tcl_warp_bwd: grid must be 8-byte aligned");
   TCL_REQUIRE(!g_grid || aligned(g_grid, 8), TCL_ERR_ARG, "tcl_warp_bwd: g_grid must be 8-byte aligned");
-  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536, TCL_ERR_SHAPE, "tcl_warp_bwd: too many images for one launch (%ld)", (long)(NB * NF));
+  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536 && cdiv(H, TILE_H) < 65536, TCL_ERR_SHAPE, "tcl_warp_bwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   if (!g_x && !g_grid && !g_theta) return TCL_OK;
   const int N = (int)(NB * NF);
-  const int per = bwd_blocks_per_image(H * W, N);
+  const int per = (int)(cdiv(W, TILE_W) * cdiv(H, TILE_H));
   float *partial = nullptr;
   if (g_theta) {
     const size_t need = tcl_warp_bwd_workspace_bytes(NB, NF, H, W, 1);
@@ -266,12 +362,14 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
     partial = (float *)workspace;
   }
   WarpBwdArgs a{grad_x_out, go_sb, go_sf, go_sc, x, x_sb, x_sf, x_sc, grid, theta, g_x, gx_sb, gx_sf, gx_sc,
-                g_grid, partial, (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners};
+                g_grid, partial, (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, lin_step(W), lin_step(H),
+                (unsigned)cdiv(W, TILE_W), (unsigned)cdiv(H, TILE_H)};
+  TCL_REQUIRE((int64_t)per * N < (1LL << 31), TCL_ERR_SHAPE, "tcl_warp_bwd: grid too large");
   hipStream_t s = (hipStream_t)stream;
   if (theta)
-    hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3(per, N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3((unsigned)per * N), dim3(TILE_W, TILE_H), 0, s, a);
   else
-    hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3(per, N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3((unsigned)per * N), dim3(TILE_W, TILE_H), 0, s, a);
   int rc = check_launch("tcl_warp_bwd");
   if (rc != TCL_OK) return rc;
   if (g_theta) {
