@@ -312,6 +312,218 @@ static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
   return check_launch(what);
 }
 
+// ------------------------------------------------------------------------------------------ bf16 MFMA GEMM
+// Same contract as gemm_f32_kernel (fp32 operands in global memory, fp32 accumulate and output), but the products
+// run on v_mfma_f32_32x32x16_bf16.  Operands are converted while they are staged into LDS:
+//   NS = 1 (TCL_PREC_BF16)  : x -> bf16(x)                                   one MFMA per fragment pair
+//   NS = 2 (TCL_PREC_BF16X3): x -> hi = bf16(x), lo = bf16(x - hi)           hi*hi + hi*lo + lo*hi (fp32-class)
+// LDS images (bf16), one per operand and split level:
+//   KC operand (k contiguous in global):  [row][k], 80-byte rows  -> fragment = one ds_read_b128 (conflict-free)
+//   MC operand (row contiguous in global): [k][row], row stride = ROWS + 32 elements -> fragment = two
+//     ds_read_b64_tr_b16 (the hardware transposing read; conflict-free at this stride), so that neither the
+//     NCHW feature planes nor the cotangent volume ever need a transposed copy in HBM.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int BKH = 32;            // k depth of one staged tile (bf16 elements): two 32x32x16 MFMA k-steps
+constexpr int KC_LDH = BKH + 8;    // [row][k] image row (elements): 80 bytes
+template <int ROWS> struct McLd { static constexpr int value = ROWS + 32; };  // [k][row] image row (elements)
+
+template <int ROWS, bool KC> struct ImgSize { static constexpr int value = KC ? ROWS * KC_LDH : BKH * McLd<ROWS>::value; };
+
+template <int ROWS, int NT, bool KC, bool VEC, int NS>
+struct TileLoaderH {
+  static constexpr int NV = ROWS * BKH / 4 / NT;  // float4 per thread
+  static_assert(ROWS * BKH / 4 % NT == 0, "tile must divide over the block");
+  f32x4 r[NV];
+
+  __device__ __forceinline__ void load(const float *base, int64_t ld, int row0, int k0, int rows, int depth, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      int row, k;
+      if (KC) { row = idx / (BKH / 4); k = (idx % (BKH / 4)) * 4; }
+      else    { k = idx / (ROWS / 4); row = (idx % (ROWS / 4)) * 4; }
+      const int gr = row0 + row, gk = k0 + k;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (KC) {
+        if (gr < rows) {
+          const float *p = base + (int64_t)gr * ld + gk;
+          if (VEC) { if (gk < depth) val = *reinterpret_cast<const f32x4 *>(p); }
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (gk + e < depth) val[e] = p[e];
+          }
+        }
+      } else {
+        if (gk < depth) {
+          const float *p = base + (int64_t)gk * ld + gr;
+          if (VEC) { if (gr < rows) val = *reinterpret_cast<const f32x4 *>(p); }
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (gr + e < rows) val[e] = p[e];
+          }
+        }
+      }
+      r[i] = val;
+    }
+  }
+
+  // img_hi / img_lo: the operand's LDS images (lo unused when NS == 1)
+  __device__ __forceinline__ void store(__bf16 *img_hi, __bf16 *img_lo, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      int off;
+      if (KC) { const int row = idx / (BKH / 4), k = (idx % (BKH / 4)) * 4; off = row * KC_LDH + k; }
+      else    { const int k = idx / (ROWS / 4), row = (idx % (ROWS / 4)) * 4; off = k * McLd<ROWS>::value + row; }
+      bf16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (__bf16)r[i][e];
+      *reinterpret_cast<bf16x4 *>(img_hi + off) = h;
+      if (NS == 2) {
+        bf16x4 l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l[e] = (__bf16)(r[i][e] - (float)h[e]);
+        *reinterpret_cast<bf16x4 *>(img_lo + off) = l;
+      }
+    }
+  }
+};
+
+// fragment of the 32x32x16 MFMA for the 32 rows starting at row0, k-step ks (0/1) of the staged tile:
+// lane (r = lane & 31, h = lane >> 5) gets element (row0 + r, k = 16 ks + 8 h + j), j = 0..7.
+template <int ROWS, bool KC>
+__device__ __forceinline__ bf16x8 read_frag_h(const __bf16 *img, int row0, int ks, int lane) {
+  if (KC) return *reinterpret_cast<const bf16x8 *>(img + (row0 + (lane & 31)) * KC_LDH + ks * 16 + (lane >> 5) * 8);
+  // transposing read: per 16-lane group a 4 (k) x 16 (row) block, lane 4q+p supplies (k row q, rows 4p..4p+3) and
+  // receives row (lane & 15) of the block for the 4 k's.  Groups 0/1 = rows 0-15 / 16-31 at h = 0, groups 2/3 at h = 1.
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const __bf16 *a = img + (ks * 16 + (g >> 1) * 8 + q) * McLd<ROWS>::value + row0 + (g & 1) * 16 + 4 * p;
+  const s16x4 k03 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)a);
+  const s16x4 k47 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(a + 4 * McLd<ROWS>::value));
+  // whole-vector reinterpretation (an element-wise bit_cast loop is mis-lowered by hipcc 7.2: it duplicates element 0)
+  const s16x8 both = __builtin_shufflevector(k03, k47, 0, 1, 2, 3, 4, 5, 6, 7);
+  const bf16x8 f = __builtin_bit_cast(bf16x8, both);
+  return f;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int NS>
+__global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_IMG = ImgSize<BM, A_KC>::value, B_IMG = ImgSize<BN, B_KC>::value;
+  __shared__ __attribute__((aligned(16))) __bf16 smem[NS * (A_IMG + B_IMG)];
+  __bf16 *Ah = smem, *Al = smem + (NS - 1) * A_IMG, *Bh = smem + NS * A_IMG, *Bl = Bh + (NS - 1) * B_IMG;
+
+  const unsigned per_batch = g.tiles_m * g.tiles_n;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned z = lin / per_batch, local = lin - z * per_batch;
+  constexpr unsigned GROUP = 8;
+  const unsigned gw = GROUP * g.tiles_n;
+  const unsigned gid = local / gw, first_m = gid * GROUP;
+  const unsigned gsz = min((unsigned)g.tiles_m - first_m, GROUP);
+  const unsigned tm = first_m + (local % gw) % gsz, tn = (local % gw) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const float *Ab = g.A + (int64_t)(z / g.a_bdiv) * g.a_bs;
+  const float *Bb = g.B + (int64_t)z * g.b_bs;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TileLoaderH<BM, NT, A_KC, VEC, NS> la;
+  TileLoaderH<BN, NT, B_KC, VEC, NS> lb;
+  const int ktiles = (g.K + BKH - 1) / BKH;
+  const int total = ktiles * g.nseg;
+
+  la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
+  lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
+  for (int t = 0; t < total; ++t) {
+    la.store(Ah, Al, tid);
+    lb.store(Bh, Bl, tid);
+    __syncthreads();
+    if (t + 1 < total) {
+      const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
+      la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BKH, g.M, g.K, tid);
+      lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BKH, g.N, g.K, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BKH / 16; ++ks) {
+      bf16x8 ah[TM], bh[TN], al[TM], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = read_frag_h<BM, A_KC>(Ah, wm0 + i * 32, ks, lane);
+        if (NS == 2) al[i] = read_frag_h<BM, A_KC>(Al, wm0 + i * 32, ks, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = read_frag_h<BN, B_KC>(Bh, wn0 + j * 32, ks, lane);
+        if (NS == 2) bl[j] = read_frag_h<BN, B_KC>(Bl, wn0 + j * 32, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (NS == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  float *Db = g.D + (int64_t)z * g.d_bs;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + j * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < g.M && n < g.N) Db[(int64_t)m * g.d_ld + n] = acc[i][j][r];
+      }
+    }
+}
+
+static bool gemm_vec_ok(const GemmArgs &g, bool a_kc, bool b_kc) {
+  return aligned(g.A, 16) && aligned(g.B, 16) && g.a_ld % 4 == 0 && g.b_ld % 4 == 0 && g.a_bs % 4 == 0 && g.b_bs % 4 == 0 &&
+         g.a_ss % 4 == 0 && g.b_ss % 4 == 0 && (a_kc ? g.K % 4 == 0 : g.M % 4 == 0) && (b_kc ? g.K % 4 == 0 : g.N % 4 == 0);
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+static int launch_gemm_bf16(GemmArgs g, int nsplit, hipStream_t s, const char *what) {
+  g.tiles_m = (int)cdiv(g.M, BM);
+  g.tiles_n = (int)cdiv(g.N, BN);
+  const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
+  TCL_REQUIRE(blocks > 0 && blocks < (1LL << 31), TCL_ERR_SHAPE, "%s: grid of %ld blocks", what, (long)blocks);
+  const bool vec = gemm_vec_ok(g, A_KC, B_KC);
+  const dim3 grd((unsigned)blocks), blk(WM * WN * 64);
+  if (nsplit == 2) {
+    if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 2>), grd, blk, 0, s, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, false, 2>), grd, blk, 0, s, g);
+  } else {
+    if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 1>), grd, blk, 0, s, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, false, 1>), grd, blk, 0, s, g);
+  }
+  return check_launch(what);
+}
+
 // ------------------------------------------------------------------------------------------ workspace layout
 struct CorrWs {
   float *a_hat, *r_hat, *n_t, *n_r;
@@ -427,7 +639,8 @@ extern "C" size_t tcl_corr4d_fwd_workspace_bytes(int64_t B, int64_t C, int64_t F
 static int corr_check(const char *fn, int64_t B, int64_t C, int64_t F, int64_t P, int precision) {
   TCL_REQUIRE(B > 0 && C > 0 && F > 0 && P > 0, TCL_ERR_SHAPE, "%s: bad shape B=%ld C=%ld F=%ld P=%ld", fn, (long)B, (long)C, (long)F, (long)P);
   TCL_REQUIRE(B * F < 65536 && P < (1 << 24) && C < (1 << 20), TCL_ERR_SHAPE, "%s: shape out of range", fn);
-  TCL_REQUIRE(precision == TCL_PREC_F32, TCL_ERR_UNSUPPORTED, "%s: precision %d is not built in this version", fn, precision);
+  TCL_REQUIRE(precision == TCL_PREC_F32 || precision == TCL_PREC_BF16 || precision == TCL_PREC_BF16X3, TCL_ERR_UNSUPPORTED,
+              "%s: unknown precision %d", fn, precision);
   return TCL_OK;
 }
 
@@ -462,6 +675,8 @@ extern "C" int tcl_corr4d_contract(const void *fwd_workspace, float *out, int64_
   g.a_ld = P; g.b_ld = P; g.d_ld = P;
   g.a_bs = C * P; g.b_bs = C * P; g.d_bs = P * P;
   g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
+  if (precision != TCL_PREC_F32)
+    return launch_gemm_bf16<128, 128, 2, 2, false, false>(g, precision == TCL_PREC_BF16X3 ? 2 : 1, (hipStream_t)stream, "tcl_corr4d_contract(bf16 gemm)");
   return launch_gemm<128, 128, 2, 2, false, false>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
 }
 
@@ -526,6 +741,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
   float *d_a = (float *)workspace;
   float *d_r = (float *)((char *)workspace + round_up((size_t)B * C * P * 4, 256));
   const dim3 blk(256);
+  const int nsplit = precision == TCL_PREC_BF16X3 ? 2 : 1;
   if (g_x_t) {
     // d_a^[b][c][p] = sum_f sum_q r^[b,f][c][q] G[b,f][p][q]      (M = C, N = P, K = P per reference frame)
     GemmArgs g{};
@@ -534,7 +750,8 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_ld = P; g.b_ld = P; g.d_ld = P;
     g.a_bs = F * C * P; g.b_bs = F * P * P; g.d_bs = C * P;
     g.a_ss = C * P; g.b_ss = P * P; g.a_bdiv = 1; g.nbatch = (int)B;
-    rc = launch_gemm<256, 128, 4, 2, true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
+    if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, true>(g, nsplit, s, "tcl_corr4d_bwd(d_a bf16 gemm)");
+    else rc = launch_gemm<256, 128, 4, 2, true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
     if (rc) return rc;
     hipLaunchKernelGGL(corr_normalise_bwd_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)B), blk, 0, s, x_t, v_t, d_a, w.n_t, g_x_t, (int)C, 1, (int)P);
     rc = check_launch("tcl_corr4d_bwd(normalise bwd, target)");
@@ -548,7 +765,8 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_ld = P; g.b_ld = P; g.d_ld = P;
     g.a_bs = C * P; g.b_bs = P * P; g.d_bs = C * P;
     g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
-    rc = launch_gemm<256, 128, 4, 2, true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
+    if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, false>(g, nsplit, s, "tcl_corr4d_bwd(d_r bf16 gemm)");
+    else rc = launch_gemm<256, 128, 4, 2, true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
     if (rc) return rc;
     hipLaunchKernelGGL(corr_normalise_bwd_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)(B * F)), blk, 0, s, x_r, v_r, d_r, w.n_r, g_x_r, (int)C, (int)F, (int)P);
     rc = check_launch("tcl_corr4d_bwd(normalise bwd, refs)");
