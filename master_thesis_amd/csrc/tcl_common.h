@@ -43,6 +43,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // Bijective XCD-aware remap of a 1-D block id: blocks are dealt round-robin over the 8 XCDs, so give each
 // XCD a contiguous chunk of the logical tile order (neighbouring tiles then share one L2).
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+#ifdef TCL_NO_XCD_REMAP
+  return bid;
+#endif
   const unsigned q = nblk / kNumXCD, r = nblk % kNumXCD;
   const unsigned xcd = bid % kNumXCD, idx = bid / kNumXCD;
   const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;

@@ -49,12 +49,12 @@ __device__ __forceinline__ Taps make_taps(float ix, float iy, int H, int W) {
   t.sw = __fmul_rn(t.ny, t.ex);
   t.se = __fmul_rn(t.ny, t.wx);
   // bounds in the float domain (NaN / huge coordinates are simply out of bounds)
-  t.xw = (x0 >= 0.f) && (x0 <= (float)(W - 1));
-  t.xe = (x0 >= -1.f) && (x0 <= (float)(W - 2));
-  t.yn = (y0 >= 0.f) && (y0 <= (float)(H - 1));
-  t.ys = (y0 >= -1.f) && (y0 <= (float)(H - 2));
-  t.xi = (t.xw || t.xe) ? (int)x0 : 0;
-  t.yi = (t.yn || t.ys) ? (int)y0 : 0;
+  t.xw = (x0 >= 0.f) & (x0 <= (float)(W - 1));
+  t.xe = (x0 >= -1.f) & (x0 <= (float)(W - 2));
+  t.yn = (y0 >= 0.f) & (y0 <= (float)(H - 1));
+  t.ys = (y0 >= -1.f) & (y0 <= (float)(H - 2));
+  t.xi = (t.xw | t.xe) ? (int)x0 : 0;
+  t.yi = (t.yn | t.ys) ? (int)y0 : 0;
   t.xa = max(0, min(t.xi, W - 2));
   t.ya = max(0, min(t.yi, H - 1));
   t.yb = max(0, min(t.yi + 1, H - 1));
@@ -82,10 +82,10 @@ __device__ __forceinline__ TapVals fetch_taps(const float *plane, const Taps &t,
 template <bool W2>
 __device__ __forceinline__ void select_taps(const TapVals &v, const Taps &t, float &a, float &b, float &c, float &d) {
   const bool same = !W2 || t.xi == t.xa;   // false only at xi = -1 (east = .a) and xi = W-1 (west = .b)
-  a = (t.yn && t.xw) ? (same ? v.n.a : v.n.b) : 0.f;
-  b = (t.yn && t.xe) ? (same ? v.n.b : v.n.a) : 0.f;
-  c = (t.ys && t.xw) ? (same ? v.s.a : v.s.b) : 0.f;
-  d = (t.ys && t.xe) ? (same ? v.s.b : v.s.a) : 0.f;
+  a = (t.yn & t.xw) ? (same ? v.n.a : v.n.b) : 0.f;
+  b = (t.yn & t.xe) ? (same ? v.n.b : v.n.a) : 0.f;
+  c = (t.ys & t.xw) ? (same ? v.s.a : v.s.b) : 0.f;
+  d = (t.ys & t.xe) ? (same ? v.s.b : v.s.a) : 0.f;
 }
 
 __device__ __forceinline__ float blend(float a, float b, float c, float d, const Taps &t) {
@@ -128,77 +128,83 @@ __device__ __forceinline__ void sample_pos(const float *grid, const float *theta
 #define TCL_TILE_W 64
 #endif
 constexpr int TILE_W = TCL_TILE_W, TILE_H = 256 / TCL_TILE_W;  // 256 threads per block; a wave covers 64 consecutive pixels of one row
-constexpr int FWD_PPT = 2;              // rows per lane in the forward kernel
 constexpr int FWD_MAXC = 3;             // channels whose taps are fetched together (straight-line loads)
 
-// grid (ceil(W/64), ceil(H/(4*PPT)), NB*NF), block (64,4); lane (tx,ty) owns rows by*4*PPT + ty + 4k.
-// Phases: positions -> ALL tap loads (unconditional, clamped addresses) -> selects + blend -> predicated stores.
-template <bool HAS_THETA, bool W2>
+// 2-D grid (chunk of 256 consecutive pixels of the flattened image, image), block 256: one output pixel per lane,
+// straight-line code.
+// Order: position -> ALL tap loads of the pixel (visibility + up to three channels, unconditional, clamped addresses)
+// -> selects + blend -> stores.  No XCD remap (nothing is shared between blocks; round-robin placement keeps the
+// eight XCDs streaming through the same DRAM pages) and no data-dependent branches: hipcc drains every outstanding
+// load at a branch join, which costs a memory round trip (measured: 4.0 -> 4.9 TB/s on align_set at 256x256).
+// VMODE and C3 (C == 3, the reference's frames) are template parameters for the same reason.
+template <bool HAS_THETA, bool W2, int VMODE, bool C3>
 __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
-  // 1-D grid, XCD-contiguous: tiles that share source cache lines (neighbours in x / y, same image) run on one XCD's L2
-  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned bx = lin % a.tiles_x, rest = lin / a.tiles_x, by = rest % a.tiles_y;
-  const int n = rest / a.tiles_y, b = n / a.NF, f = n - b * a.NF;
-  const int x = bx * TILE_W + threadIdx.x;
-  if (x >= a.W) return;
-  const int ybase = by * (TILE_H * FWD_PPT) + threadIdx.y;
+  const int n = blockIdx.y, b = n / a.NF, f = n - b * a.NF;
+  const int H = a.H, W = a.W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;   // flattened: every wave reads / writes 256 contiguous, aligned bytes per plane
+  if (pix >= H * W) return;
+  const int y = pix / W, x = pix - y * W;
   const bool ac = a.align_corners != 0;
-  Taps t[FWD_PPT];
-  float ixs[FWD_PPT], iys[FWD_PPT];
-#pragma unroll
-  for (int k = 0; k < FWD_PPT; ++k) {
-    const int y = min(ybase + k * TILE_H, a.H - 1);   // rows past the image recompute the last row; their stores are skipped
-    float xs, ys;
-    sample_pos<HAS_THETA>(a.grid, a.theta, n, y, x, a.H, a.W, a.stepx, a.stepy, ac, ixs[k], iys[k], xs, ys);
-    t[k] = make_taps(ixs[k], iys[k], a.H, a.W);
+  float gx, gy;
+  if (HAS_THETA) {
+    const float *th = a.theta + (int64_t)n * 6;
+    const float xs = base_coord_step(x, W, a.stepx, ac), ys = base_coord_step(y, H, a.stepy, ac);
+    gx = __fadd_rn(__fadd_rn(__fmul_rn(th[0], xs), __fmul_rn(th[1], ys)), th[2]);
+    gy = __fadd_rn(__fadd_rn(__fmul_rn(th[3], xs), __fmul_rn(th[4], ys)), th[5]);
+  } else {
+    const float2 g = reinterpret_cast<const float2 *>(a.grid)[(int64_t)n * H * W + pix];
+    gx = g.x; gy = g.y;
   }
+  const float ix = unnormalise(gx, W, ac), iy = unnormalise(gy, H, ac);
+  const Taps t = make_taps(ix, iy, H, W);
   const float *vp = a.v + b * a.v_sb + f * a.v_sf;
-  float vr[FWD_PPT];
-  if (a.v_mode == TCL_VMODE_NEAREST) {
-#pragma unroll
-    for (int k = 0; k < FWD_PPT; ++k) {
-      const float xn = rintf(ixs[k]), yn = rintf(iys[k]);  // v_rndne: half to even, as std::nearbyint
-      const bool inb = (xn >= 0.f) && (xn <= (float)(a.W - 1)) && (yn >= 0.f) && (yn <= (float)(a.H - 1));
-      const float val = vp[(inb ? (int)yn : 0) * a.W + (inb ? (int)xn : 0)];   // unconditional load, then select
-      vr[k] = inb ? val : 0.f;
-    }
-  } else if (a.v_mode == TCL_VMODE_BILINEAR_THRESHOLD) {
-#pragma unroll
-    for (int k = 0; k < FWD_PPT; ++k) {
-      float p, q, r, s;
-      load_taps<W2>(vp, t[k], a.W, p, q, r, s);
-      vr[k] = blend(p, q, r, s, t[k]) > 0.5f ? 1.f : 0.f;
-    }
+  const float *xp = a.x + b * a.x_sb + f * a.x_sf;
+  float *op = a.xo + b * a.xo_sb + f * a.xo_sf + pix;
+  // ---- loads
+  float vnear = 0.f;
+  bool inb = false;
+  TapVals tvv, tv[FWD_MAXC];
+  if (VMODE == TCL_VMODE_NEAREST) {
+    const float xn = rintf(ix), yn = rintf(iy);  // v_rndne: half to even, as std::nearbyint
+    inb = (xn >= 0.f) & (xn <= (float)(W - 1)) & (yn >= 0.f) & (yn <= (float)(H - 1));
+    vnear = vp[(inb ? (int)yn : 0) * W + (inb ? (int)xn : 0)];   // unconditional load, then select
+  } else if (VMODE == TCL_VMODE_BILINEAR_THRESHOLD) {
+    tvv = fetch_taps<W2>(vp, t, W);
   }
-  if (a.xo) {
-    const float *xp = a.x + b * a.x_sb + f * a.x_sf;
-    float *op = a.xo + b * a.xo_sb + f * a.xo_sf + x;
+  if (C3) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tv[c] = fetch_taps<W2>(xp + c * a.x_sc, t, W);
+  }
+  // ---- visibility
+  if (VMODE != TCL_VMODE_NONE) {
+    float vr;
+    if (VMODE == TCL_VMODE_NEAREST) vr = inb ? vnear : 0.f;
+    else {
+      float p, q, r, s;
+      select_taps<W2>(tvv, t, p, q, r, s);
+      vr = blend(p, q, r, s, t) > 0.5f ? 1.f : 0.f;
+    }
+    a.vo[b * a.vo_sb + f * a.vo_sf + pix] = vr;
+  }
+  // ---- image channels
+  if (C3) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float p, q, r, s;
+      select_taps<W2>(tv[c], t, p, q, r, s);
+      op[c * a.xo_sc] = blend(p, q, r, s, t);
+    }
+  } else if (a.xo) {
     for (int c0 = 0; c0 < a.C; c0 += FWD_MAXC) {
-      TapVals tv[FWD_MAXC][FWD_PPT];
+#pragma unroll
+      for (int c = 0; c < FWD_MAXC; ++c) tv[c] = fetch_taps<W2>(xp + min(c0 + c, a.C - 1) * a.x_sc, t, W);
 #pragma unroll
       for (int c = 0; c < FWD_MAXC; ++c) {
-        const float *plane = xp + min(c0 + c, a.C - 1) * a.x_sc;
-#pragma unroll
-        for (int k = 0; k < FWD_PPT; ++k) tv[c][k] = fetch_taps<W2>(plane, t[k], a.W);
+        float p, q, r, s;
+        select_taps<W2>(tv[c], t, p, q, r, s);
+        const float val = blend(p, q, r, s, t);
+        if (c0 + c < a.C) op[(c0 + c) * a.xo_sc] = val;
       }
-#pragma unroll
-      for (int c = 0; c < FWD_MAXC; ++c)
-#pragma unroll
-        for (int k = 0; k < FWD_PPT; ++k) {
-          float p, q, r, s;
-          select_taps<W2>(tv[c][k], t[k], p, q, r, s);
-          const float val = blend(p, q, r, s, t[k]);
-          const int y = ybase + k * TILE_H;
-          if (c0 + c < a.C && y < a.H) op[(c0 + c) * a.xo_sc + y * a.W] = val;
-        }
-    }
-  }
-  if (a.v_mode != TCL_VMODE_NONE) {
-    float *vo = a.vo + b * a.vo_sb + f * a.vo_sf + x;
-#pragma unroll
-    for (int k = 0; k < FWD_PPT; ++k) {
-      const int y = ybase + k * TILE_H;
-      if (y < a.H) vo[y * a.W] = vr[k];
     }
   }
 }
@@ -319,18 +325,31 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
   TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536 && cdiv(H, TILE_H) < 65536, TCL_ERR_SHAPE, "tcl_warp_fwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   WarpArgs a{x, x_sb, x_sf, x_sc, v, v_sb, v_sf, grid, theta, x_out, xo_sb, xo_sf, xo_sc, v_out, vo_sb, vo_sf,
              (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H),
-             (unsigned)cdiv(W, TILE_W), (unsigned)cdiv(H, TILE_H * FWD_PPT)};
+             (unsigned)cdiv(W, TILE_W), (unsigned)cdiv(H, TILE_H)};
   hipStream_t s = (hipStream_t)stream;
-  const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * NB * NF;
-  TCL_REQUIRE(nblocks < (1LL << 31), TCL_ERR_SHAPE, "tcl_warp_fwd: grid too large");
-  const dim3 grd((unsigned)nblocks), blk(TILE_W, TILE_H);
+  TCL_REQUIRE((int64_t)a.tiles_x * a.tiles_y < (1LL << 31), TCL_ERR_SHAPE, "tcl_warp_fwd: grid too large");
+  const dim3 grd((unsigned)cdiv(H * W, 256), (unsigned)(NB * NF)), blk(256);
+  const bool c3 = x_out != nullptr && C == 3;
+#define TCL_LAUNCH_WARP(TH, W2, VM)                                                                  \
+  do {                                                                                                \
+    if (c3) hipLaunchKernelGGL((warp_fwd_kernel<TH, W2, VM, true>), grd, blk, 0, s, a);               \
+    else hipLaunchKernelGGL((warp_fwd_kernel<TH, W2, VM, false>), grd, blk, 0, s, a);                 \
+  } while (0)
+#define TCL_LAUNCH_WARP_V(TH, W2)                                                                    \
+  do {                                                                                                \
+    if (v_mode == TCL_VMODE_NEAREST) TCL_LAUNCH_WARP(TH, W2, TCL_VMODE_NEAREST);                      \
+    else if (v_mode == TCL_VMODE_BILINEAR_THRESHOLD) TCL_LAUNCH_WARP(TH, W2, TCL_VMODE_BILINEAR_THRESHOLD); \
+    else TCL_LAUNCH_WARP(TH, W2, TCL_VMODE_NONE);                                                     \
+  } while (0)
   if (theta) {
-    if (W >= 2) hipLaunchKernelGGL((warp_fwd_kernel<true, true>), grd, blk, 0, s, a);
-    else hipLaunchKernelGGL((warp_fwd_kernel<true, false>), grd, blk, 0, s, a);
+    if (W >= 2) TCL_LAUNCH_WARP_V(true, true);
+    else TCL_LAUNCH_WARP_V(true, false);
   } else {
-    if (W >= 2) hipLaunchKernelGGL((warp_fwd_kernel<false, true>), grd, blk, 0, s, a);
-    else hipLaunchKernelGGL((warp_fwd_kernel<false, false>), grd, blk, 0, s, a);
+    if (W >= 2) TCL_LAUNCH_WARP_V(false, true);
+    else TCL_LAUNCH_WARP_V(false, false);
   }
+#undef TCL_LAUNCH_WARP_V
+#undef TCL_LAUNCH_WARP
   return check_launch("tcl_warp_fwd");
 }
 
