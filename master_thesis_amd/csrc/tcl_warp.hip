@@ -21,7 +21,6 @@ struct WarpArgs {
   int NB, NF, C, H, W;
   int align_corners, v_mode;
   float stepx, stepy;  // 2/(W-1), 2/(H-1) (torch.linspace step), divided on the host
-  unsigned tiles_x, tiles_y;
 };
 
 __device__ __forceinline__ float unnormalise(float g, int size, bool align_corners) {
@@ -124,10 +123,6 @@ __device__ __forceinline__ void sample_pos(const float *grid, const float *theta
   iy = unnormalise(gy, H, ac);
 }
 
-#ifndef TCL_TILE_W
-#define TCL_TILE_W 64
-#endif
-constexpr int TILE_W = TCL_TILE_W, TILE_H = 256 / TCL_TILE_W;  // 256 threads per block; a wave covers 64 consecutive pixels of one row
 constexpr int FWD_MAXC = 3;             // channels whose taps are fetched together (straight-line loads)
 
 // 2-D grid (chunk of 256 consecutive pixels of the flattened image, image), block 256: one output pixel per lane,
@@ -219,70 +214,73 @@ struct WarpBwdArgs {
   int NB, NF, C, H, W;
   int align_corners;
   float stepx, stepy;
-  unsigned tiles_x, tiles_y;
 };
 
-// grid (ceil(W/64), ceil(H/4), NB*NF), block (64,4)
-template <bool HAS_THETA>
+// 2-D grid (chunk of 256 consecutive pixels of the flattened image, image), block 256; same straight-line structure as
+// the forward kernel: position -> cotangents and taps of up to three channels in flight together -> gradients.
+// HAS_GX adds the scatter-add of the input gradient (float atomics into a zeroed buffer).
+template <bool HAS_THETA, bool HAS_GX, bool W2, bool C3>
 __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
-  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned bx = lin % a.tiles_x, rest = lin / a.tiles_x, by = rest % a.tiles_y;
-  const int n = rest / a.tiles_y, b = n / a.NF, f = n - b * a.NF;
-  const int x = bx * TILE_W + threadIdx.x, y = by * TILE_H + threadIdx.y;
-  const bool ok = x < a.W && y < a.H;
+  const int n = blockIdx.y, b = n / a.NF, f = n - b * a.NF;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int pix0 = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = pix0 < HW;
+  const int pix = ok ? pix0 : HW - 1;          // lanes past the image repeat its last pixel; nothing of theirs is stored
+  const int y = pix / W, x = pix - y * W;
   const bool ac = a.align_corners != 0;
-  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (ok) {
-    const int HW = a.H * a.W, pix = y * a.W + x;
-    const float mx = ac ? 0.5f * (float)(a.W - 1) : 0.5f * (float)a.W;
-    const float my = ac ? 0.5f * (float)(a.H - 1) : 0.5f * (float)a.H;
-    const float *xp = a.x + b * a.x_sb + f * a.x_sf;
-    const float *gp = a.go + b * a.go_sb + f * a.go_sf;
-    float *gxp = a.gx ? a.gx + b * a.gx_sb + f * a.gx_sf : nullptr;
-    float ix, iy, xs, ys;
-    sample_pos<HAS_THETA>(a.grid, a.theta, n, y, x, a.H, a.W, a.stepx, a.stepy, ac, ix, iy, xs, ys);
-    const Taps t = make_taps(ix, iy, a.H, a.W);
-    const int o_nw = t.yi * a.W + t.xi;
-    float gix = 0.f, giy = 0.f;
-    for (int c = 0; c < a.C; ++c) {
-      const float g = gp[c * a.go_sc + pix];
+  const float mx = ac ? 0.5f * (float)(W - 1) : 0.5f * (float)W;
+  const float my = ac ? 0.5f * (float)(H - 1) : 0.5f * (float)H;
+  const float *xp = a.x + b * a.x_sb + f * a.x_sf;
+  const float *gp = a.go + b * a.go_sb + f * a.go_sf + pix;
+  float ix, iy, xs, ys;
+  sample_pos<HAS_THETA>(a.grid, a.theta, n, y, x, H, W, a.stepx, a.stepy, ac, ix, iy, xs, ys);
+  const Taps t = make_taps(ix, iy, H, W);
+  float gix = 0.f, giy = 0.f;
+  const int C = C3 ? 3 : a.C;   // C3: the reference's frames; the loop below then is one straight-line pass
+  for (int c0 = 0; c0 < C; c0 += FWD_MAXC) {
+    float g[FWD_MAXC];
+    TapVals tv[FWD_MAXC];
+#pragma unroll
+    for (int c = 0; c < FWD_MAXC; ++c) {
+      const int cc = min(c0 + c, C - 1);
+      g[c] = gp[cc * a.go_sc];
+      tv[c] = fetch_taps<W2>(xp + cc * a.x_sc, t, W);
+    }
+#pragma unroll
+    for (int c = 0; c < FWD_MAXC; ++c) {
       float vnw, vne, vsw, vse;
-      if (a.W >= 2) load_taps<true>(xp + c * a.x_sc, t, a.W, vnw, vne, vsw, vse);
-      else load_taps<false>(xp + c * a.x_sc, t, a.W, vnw, vne, vsw, vse);
-      gix += g * ((vne - vnw) * t.sy + (vse - vsw) * t.ny);
-      giy += g * ((vsw - vnw) * t.ex + (vse - vne) * t.wx);
-      if (gxp) {
-        float *gplane = gxp + c * a.gx_sc + o_nw;
-        if (t.xw && t.yn) atomicAdd(gplane, g * t.nw);
-        if (t.xe && t.yn) atomicAdd(gplane + 1, g * t.ne);
-        if (t.xw && t.ys) atomicAdd(gplane + a.W, g * t.sw);
-        if (t.xe && t.ys) atomicAdd(gplane + a.W + 1, g * t.se);
+      select_taps<W2>(tv[c], t, vnw, vne, vsw, vse);
+      const float gc = (c0 + c < C) ? g[c] : 0.f;
+      gix += gc * ((vne - vnw) * t.sy + (vse - vsw) * t.ny);
+      giy += gc * ((vsw - vnw) * t.ex + (vse - vne) * t.wx);
+      if (HAS_GX) {
+        if (ok & (c0 + c < C)) {
+          float *gplane = a.gx + b * a.gx_sb + f * a.gx_sf + (c0 + c) * a.gx_sc + t.yi * W + t.xi;
+          if (t.xw & t.yn) atomicAdd(gplane, gc * t.nw);
+          if (t.xe & t.yn) atomicAdd(gplane + 1, gc * t.ne);
+          if (t.xw & t.ys) atomicAdd(gplane + W, gc * t.sw);
+          if (t.xe & t.ys) atomicAdd(gplane + W + 1, gc * t.se);
+        }
       }
     }
-    gix *= mx;
-    giy *= my;
-    if (HAS_THETA) {
-      acc[0] = gix * xs; acc[1] = gix * ys; acc[2] = gix;
-      acc[3] = giy * xs; acc[4] = giy * ys; acc[5] = giy;
-    } else if (a.g_grid) {
-      reinterpret_cast<float2 *>(a.g_grid)[(int64_t)n * HW + pix] = make_float2(gix, giy);
-    }
   }
-  if (HAS_THETA && a.partial) {
-    __shared__ float red[4][6];
-    const int tid = threadIdx.y * TILE_W + threadIdx.x;
+  gix *= mx;
+  giy *= my;
+  if (HAS_THETA) {
+    if (a.partial) {
+      float acc[6] = {gix * xs, gix * ys, gix, giy * xs, giy * ys, giy};
+      __shared__ float red[4][6];
+      const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const float s = wave_sum(acc[k]);
-      if ((tid & 63) == 0) red[tid >> 6][k] = s;
+      for (int k = 0; k < 6; ++k) {
+        const float s = wave_sum(ok ? acc[k] : 0.f);
+        if ((tid & 63) == 0) red[tid >> 6][k] = s;
+      }
+      __syncthreads();
+      if (tid < 6) a.partial[((int64_t)n * gridDim.x + blockIdx.x) * 6 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }
-    __syncthreads();
-    if (tid < 6) {
-      const int k = tid;
-      const float s = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-      const int64_t blk = (int64_t)by * a.tiles_x + bx, nblk = (int64_t)a.tiles_x * a.tiles_y;
-      a.partial[((int64_t)n * nblk + blk) * 6 + k] = s;
-    }
+  } else if (a.g_grid) {
+    if (ok) reinterpret_cast<float2 *>(a.g_grid)[(int64_t)n * HW + pix] = make_float2(gix, giy);
   }
 }
 
@@ -322,12 +320,10 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
   TCL_REQUIRE((x_out == nullptr) || (x != nullptr && C > 0), TCL_ERR_ARG, "tcl_warp_fwd: x_out given without x");
   TCL_REQUIRE(x_out || v_mode != TCL_VMODE_NONE, TCL_ERR_ARG, "tcl_warp_fwd: nothing to compute");
   TCL_REQUIRE(!grid || aligned(grid, 8), TCL_ERR_ARG, "tcl_warp_fwd: grid must be 8-byte aligned");
-  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536 && cdiv(H, TILE_H) < 65536, TCL_ERR_SHAPE, "tcl_warp_fwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
+  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536, TCL_ERR_SHAPE, "tcl_warp_fwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   WarpArgs a{x, x_sb, x_sf, x_sc, v, v_sb, v_sf, grid, theta, x_out, xo_sb, xo_sf, xo_sc, v_out, vo_sb, vo_sf,
-             (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H),
-             (unsigned)cdiv(W, TILE_W), (unsigned)cdiv(H, TILE_H)};
+             (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H)};
   hipStream_t s = (hipStream_t)stream;
-  TCL_REQUIRE((int64_t)a.tiles_x * a.tiles_y < (1LL << 31), TCL_ERR_SHAPE, "tcl_warp_fwd: grid too large");
   const dim3 grd((unsigned)cdiv(H * W, 256), (unsigned)(NB * NF)), blk(256);
   const bool c3 = x_out != nullptr && C == 3;
 #define TCL_LAUNCH_WARP(TH, W2, VM)                                                                  \
@@ -355,7 +351,7 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
 
 extern "C" size_t tcl_warp_bwd_workspace_bytes(int64_t NB, int64_t NF, int64_t H, int64_t W, int have_theta) {
   if (!have_theta || NB <= 0 || NF <= 0 || H <= 0 || W <= 0) return 0;
-  return round_up((size_t)(NB * NF) * cdiv(W, TILE_W) * cdiv(H, TILE_H) * 6 * sizeof(float), 256);
+  return round_up((size_t)(NB * NF) * cdiv(H * W, 256) * 6 * sizeof(float), 256);
 }
 
 extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_sf, int64_t go_sc, const float *x,
@@ -369,10 +365,10 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
   TCL_REQUIRE(!(grid && g_theta) && !(theta && g_grid), TCL_ERR_ARG, "tcl_warp_bwd: gradient kind does not match the forward's source");
   TCL_REQUIRE(!grid || aligned(grid, 8), TCL_ERR_ARG, "tcl_warp_bwd: grid must be 8-byte aligned");
   TCL_REQUIRE(!g_grid || aligned(g_grid, 8), TCL_ERR_ARG, "tcl_warp_bwd: g_grid must be 8-byte aligned");
-  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536 && cdiv(H, TILE_H) < 65536, TCL_ERR_SHAPE, "tcl_warp_bwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
+  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536, TCL_ERR_SHAPE, "tcl_warp_bwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   if (!g_x && !g_grid && !g_theta) return TCL_OK;
   const int N = (int)(NB * NF);
-  const int per = (int)(cdiv(W, TILE_W) * cdiv(H, TILE_H));
+  const int per = (int)cdiv(H * W, 256);
   float *partial = nullptr;
   if (g_theta) {
     const size_t need = tcl_warp_bwd_workspace_bytes(NB, NF, H, W, 1);
@@ -381,14 +377,23 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
     partial = (float *)workspace;
   }
   WarpBwdArgs a{grad_x_out, go_sb, go_sf, go_sc, x, x_sb, x_sf, x_sc, grid, theta, g_x, gx_sb, gx_sf, gx_sc,
-                g_grid, partial, (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, lin_step(W), lin_step(H),
-                (unsigned)cdiv(W, TILE_W), (unsigned)cdiv(H, TILE_H)};
-  TCL_REQUIRE((int64_t)per * N < (1LL << 31), TCL_ERR_SHAPE, "tcl_warp_bwd: grid too large");
+                g_grid, partial, (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, lin_step(W), lin_step(H)};
   hipStream_t s = (hipStream_t)stream;
-  if (theta)
-    hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3((unsigned)per * N), dim3(TILE_W, TILE_H), 0, s, a);
-  else
-    hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3((unsigned)per * N), dim3(TILE_W, TILE_H), 0, s, a);
+  const dim3 grd((unsigned)per, (unsigned)N), blk(256);
+#define TCL_LAUNCH_WBWD(TH, GX)                                                                   \
+  do {                                                                                             \
+    if (W >= 2 && C == 3) hipLaunchKernelGGL((warp_bwd_kernel<TH, GX, true, true>), grd, blk, 0, s, a);   \
+    else if (W >= 2) hipLaunchKernelGGL((warp_bwd_kernel<TH, GX, true, false>), grd, blk, 0, s, a);       \
+    else hipLaunchKernelGGL((warp_bwd_kernel<TH, GX, false, false>), grd, blk, 0, s, a);                  \
+  } while (0)
+  if (theta) {
+    if (g_x) TCL_LAUNCH_WBWD(true, true);
+    else TCL_LAUNCH_WBWD(true, false);
+  } else {
+    if (g_x) TCL_LAUNCH_WBWD(false, true);
+    else TCL_LAUNCH_WBWD(false, false);
+  }
+#undef TCL_LAUNCH_WBWD
   int rc = check_launch("tcl_warp_bwd");
   if (rc != TCL_OK) return rc;
   if (g_theta) {
