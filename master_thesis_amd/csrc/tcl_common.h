@@ -28,6 +28,11 @@ constexpr float kNormEps = 1e-9f;
     if (!(cond)) return ::tcl::set_error((code), __VA_ARGS__); \
   } while (0)
 
+// Placed after the N global loads of a step, before their first use: asks the machine scheduler to issue all N
+// vector-memory reads of the region before anything else.  Without it hipcc pairs every load with its use
+// (`load; s_waitcnt vmcnt(0); use`) to save registers, which serialises the memory round trips.
+#define TCL_LOADS_FIRST(N) __builtin_amdgcn_sched_group_barrier(0x020, (N), 0)
+
 // wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -142,46 +142,46 @@ __global__ void __launch_bounds__(256) masked_softmax_bwd_kernel(const float *__
 }
 
 // ------------------------------------------------------------------------------------------ context matching
+// Kernel style (all of them): straight-line bodies whose loads are unconditional (indices clamped, contributions of
+// padding lanes / padding references zeroed afterwards).  A run-time condition around a load makes hipcc wait for
+// every outstanding load at the join, which serialises the memory round trips (the first version of these kernels
+// ran at 3 TB/s for that reason).  The number of references handled per pass, RU, is a template parameter.
 struct CtxWs {
   float *vt;       // (B,hw)   resized target visibility
   float *vr;       // (B,R,hw) resized reference visibility
   float *gs;       // (B,R)    similarity after normalisation / zeroing
   float *dscale;   // (B,R)    d gs / d raw sum  (0 where v_sum was zero)
-  float *partial;  // (B,R,nblk) per-block partial sums of the raw similarity
-  int nblk, csplit;
+  float *partial;  // (B,R,C) per-channel partial sums of the raw similarity
+  float *vsp;      // (B,R)   overlap area  sum_x vt*vr
+  unsigned *mbits; // (passes,B,hw) per pixel: bit 0 = vt, bit 1+k = vr of reference pass*ru + k (the similarity kernel's masks in one load)
+  int passes, ru;  // references are handled in `passes` launches of `ru` <= CTX_RMAX each
   size_t bytes;
 };
 constexpr int CTX_PXW = 64;  // lanes along the pixel axis; each lane owns PX (1 or 2) adjacent pixels
-constexpr int CTX_RC = 8;    // reference frames accumulated per pass over the channels
+constexpr int CTX_RC = 8;    // reference frames per pass in the backward match kernel
 
 static int ctx_px(int64_t hw) { return hw % 2 == 0 ? 2 : 1; }
+constexpr int CTX_RMAX = 16;  // references per launch of the slab kernels (one template instance per count); more -> several passes
+
 static int ctx_xblocks(int64_t hw) { return (int)cdiv(hw, CTX_PXW * ctx_px(hw)); }
-static int ctx_csplit(int64_t B, int64_t C, int64_t hw) {
-  // enough blocks to fill the chip (>= ~8 per CU) without making each block's channel share trivial
-  int64_t want = cdiv((int64_t)kNumCU * 8, B * ctx_xblocks(hw));
-  int64_t maxs = cdiv(C, 4 * 4);  // at least 4 channels per wave
-  if (want > maxs) want = maxs;
-  return (int)(want < 1 ? 1 : want);
-}
 
 static CtxWs ctx_ws(void *base, int64_t B, int64_t C, int64_t R, int64_t hw) {
   CtxWs w;
   size_t off = 0;
   auto take = [&](size_t n) { float *p = (float *)((char *)base + off); off += round_up(n * sizeof(float), 256); return p; };
-  w.csplit = ctx_csplit(B, C, hw);
-  w.nblk = ctx_xblocks(hw) * w.csplit;
   w.vt = take((size_t)B * hw);
   w.vr = take((size_t)B * R * hw);
   w.gs = take((size_t)B * R);
   w.dscale = take((size_t)B * R);
-  w.partial = take((size_t)B * R * w.nblk);
+  w.partial = take((size_t)B * R * C);
+  w.vsp = take((size_t)B * R);
+  w.passes = (int)cdiv(R, CTX_RMAX);
+  w.ru = (int)cdiv(R, w.passes);
+  w.mbits = (unsigned *)take((size_t)w.passes * B * hw);
   w.bytes = off;
   return w;
 }
 
-template <int PX> struct PxVec;
-template <> struct PxVec<1> { typedef float T; };
-template <> struct PxVec<2> { typedef float2 T; };
 template <int PX> __device__ __forceinline__ void ldpx(const float *p, float (&v)[PX]) {
   if (PX == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[PX - 1] = t.y; }
   else v[0] = p[0];
@@ -191,80 +191,112 @@ template <int PX> __device__ __forceinline__ void stpx(float *p, const float (&v
   else p[0] = v[0];
 }
 
-// grid (xblocks, csplit, B), block (64,4): lane = PX adjacent pixels, wave = a strided subset of the channels.
-// partial[b][r][blk] = sum over the block's (c,x) of vt*vr_r*f_t*f_r; the mask is factored out of the channel sum.
-template <int PX>
-__global__ void __launch_bounds__(256) ctx_sim_kernel(const float *__restrict__ cf, const float *__restrict__ vt,
-                                                      const float *__restrict__ vr, float *__restrict__ partial, int C, int R,
-                                                      int hw, int nblk, unsigned xblocks, unsigned csplit) {
-  // 1-D grid, XCD-contiguous (x fastest, then channel split, then target): x-neighbours share cache lines
-  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned bxi = lin % xblocks, rest = lin / xblocks, cs = rest % csplit;
-  const int b = rest / csplit, lane = threadIdx.x, wv = threadIdx.y;
-  const int x = (bxi * CTX_PXW + lane) * PX;
-  const bool ok = x < hw;
-  const int cstep = 4 * csplit, c0 = cs * 4 + wv;
-  const float *cfb = cf + (int64_t)b * C * (R + 1) * hw + x;
-  __shared__ float red[4][CTX_RC];
-  float vtx[PX];
-#pragma unroll
-  for (int k = 0; k < PX; ++k) vtx[k] = 0.f;
-  if (ok) ldpx<PX>(vt + (int64_t)b * hw + x, vtx);
-  for (int r0 = 0; r0 < R; r0 += CTX_RC) {
-    float acc[CTX_RC][PX];
-#pragma unroll
-    for (int k = 0; k < CTX_RC; ++k)
-#pragma unroll
-      for (int e = 0; e < PX; ++e) acc[k][e] = 0.f;
-    if (ok)
-      for (int c = c0; c < C; c += cstep) {
-        const float *fp = cfb + (int64_t)c * (R + 1) * hw;
-        float ft[PX];
-        ldpx<PX>(fp, ft);
-#pragma unroll
-        for (int k = 0; k < CTX_RC; ++k)
-          if (r0 + k < R) {
-            float fr[PX];
-            ldpx<PX>(fp + (int64_t)(r0 + k + 1) * hw, fr);
-#pragma unroll
-            for (int e = 0; e < PX; ++e) acc[k][e] += ft[e] * fr[e];
-          }
+// both mask resizes of the forward pass in one launch: image n of B*(R+1) is v_t[b] (j == 0) or v_aligned[b][j-1]
+__global__ void __launch_bounds__(256) ctx_resize_masks_kernel(const float *__restrict__ v_t, const float *__restrict__ v_al,
+                                                               float *__restrict__ vt, float *__restrict__ vr, unsigned *__restrict__ mbits,
+                                                               int B, int R, int H, int W, int h, int w, int passes, int ru) {
+  const float sh = __fdiv_rn((float)H, (float)h), sw = __fdiv_rn((float)W, (float)w);
+  const int hw = h * w;
+  const int64_t total = (int64_t)B * (R + 1) * hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / hw;
+    const int r = (int)(i - n * hw), y = r / w, x = r - y * w;
+    const int b = (int)(n / (R + 1)), j = (int)(n - (int64_t)b * (R + 1));
+    const LinTap ty = linear_tap(y, H, sh), tx = linear_tap(x, W, sw);
+    const float *p = j == 0 ? v_t + (int64_t)b * H * W : v_al + ((int64_t)b * R + (j - 1)) * H * W;
+    const float val = bilerp(p[ty.i0 * W + tx.i0], p[ty.i0 * W + tx.i1], p[ty.i1 * W + tx.i0], p[ty.i1 * W + tx.i1], tx, ty);
+    float *o = j == 0 ? vt + (int64_t)b * hw : vr + ((int64_t)b * R + (j - 1)) * hw;
+    const bool on = val > 0.5f;
+    o[r] = on ? 1.f : 0.f;
+    if (on) {   // mbits was zeroed on the stream before this launch
+      if (j == 0) {
+        for (int q = 0; q < passes; ++q) atomicOr(mbits + ((int64_t)q * B + b) * hw + r, 1u);
+      } else {
+        const int q = (j - 1) / ru, k = (j - 1) - q * ru;
+        atomicOr(mbits + ((int64_t)q * B + b) * hw + r, 2u << k);
       }
-#pragma unroll
-    for (int k = 0; k < CTX_RC; ++k) {
-      float s = 0.f;
-      if (ok && r0 + k < R) {
-        float m[PX];
-        ldpx<PX>(vr + ((int64_t)b * R + r0 + k) * hw + x, m);
-#pragma unroll
-        for (int e = 0; e < PX; ++e) s += acc[k][e] * (vtx[e] * m[e]);
-      }
-      s = wave_sum(s);
-      if (lane == 0) red[wv][k] = s;
     }
-    __syncthreads();
-    if (wv == 0 && lane < CTX_RC && r0 + lane < R)
-      partial[((int64_t)b * R + r0 + lane) * nblk + cs * xblocks + bxi] =
-          (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    __syncthreads();
   }
 }
 
-// one wave per (b,r): v_sum, zeros flag, normalisation.  grid = ceil(B*R/4) blocks of 4 waves.
-__global__ void __launch_bounds__(256) ctx_finalize_kernel(const float *__restrict__ vt, const float *__restrict__ vr,
-                                                           const float *__restrict__ partial, float *__restrict__ gs,
-                                                           float *__restrict__ dscale, int BR, int R, int C, int hw, int nblk,
+// One wave per (target b, channel c): it streams the contiguous (R+1) x hw slab of that channel, 64*PX pixels of all
+// R+1 frames per step (measured: the slab walk reads at 6.8 TB/s, an x-tiled channel loop at 5 TB/s).
+//   partial[b][r][c] = sum_x vt[x] vr_r[x] f_t[c,x] f_r[c,x]     vsp[b][r] = sum_x vt vr_r  (written by the c == 0 wave)
+// Sums run in a fixed order (x ascending per lane, then the wave tree): deterministic.  RU = R (template) so that the
+// per-reference accumulators live in registers.
+template <int RU, int PX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ctx_sim_kernel(const float *cf, const unsigned *mbits, float *partial, float *vsp, int B, int C,
+                                                      int hw, int R, int r0) {
+  // (no __restrict__ on purpose: it lets hipcc spread the loads among their uses)
+  // A wave owns the channel pair (c, c+1) of target b.  The wave index is made scalar so that the slab pointers live in
+  // SGPRs.  The R+1 masks of a pixel arrive as one bit field (ctx_resize_masks_kernel), not as R+1 float loads.
+  const int cpairs = (C + 1) >> 1;
+  const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= B * cpairs) return;
+  const int b = w / cpairs, c = (w - b * cpairs) * 2;
+  const bool has2 = c + 1 < C;
+  const int64_t cstride = (int64_t)(R + 1) * hw;
+  const float *s1 = cf + ((int64_t)b * C + c) * cstride, *s2 = s1 + (has2 ? cstride : 0);
+  const unsigned *mb = mbits + ((int64_t)(r0 / RU) * B + b) * hw;
+  float acc1[RU], acc2[RU], vs[RU];
+  int rr[RU];   // references r0 .. r0+RU-1 of this pass (clamped: the padding ones are loaded but never written)
+#pragma unroll
+  for (int k = 0; k < RU; ++k) { acc1[k] = acc2[k] = vs[k] = 0.f; rr[k] = min(r0 + k, R - 1); }
+  for (int x0 = lane * PX; x0 < hw + (CTX_PXW - 1) * PX; x0 += CTX_PXW * PX) {   // every lane takes the same number of steps
+    const bool ok = x0 < hw;
+    const int x = ok ? x0 : 0;
+    float t1[PX], t2[PX], f1[RU][PX], f2[RU][PX];
+    unsigned bits[PX];
+    ldpx<PX>(s1 + x, t1);
+    ldpx<PX>(s2 + x, t2);
+    if (PX == 2) { const uint2 u = *reinterpret_cast<const uint2 *>(mb + x); bits[0] = u.x; bits[PX - 1] = u.y; }
+    else bits[0] = mb[x];
+#pragma unroll
+    for (int k = 0; k < RU; ++k) {
+      ldpx<PX>(s1 + (rr[k] + 1) * hw + x, f1[k]);
+      ldpx<PX>(s2 + (rr[k] + 1) * hw + x, f2[k]);
+    }
+    TCL_LOADS_FIRST(2 * RU + 3);   // all loads of the step in flight before the first use
+#pragma unroll
+    for (int e = 0; e < PX; ++e) bits[e] = (ok && (bits[e] & 1u)) ? bits[e] : 0u;   // vt == 0 (or a padding lane): no reference counts
+#pragma unroll
+    for (int k = 0; k < RU; ++k)
+#pragma unroll
+      for (int e = 0; e < PX; ++e) {
+        const float mm = (float)((bits[e] >> (k + 1)) & 1u);
+        acc1[k] = fmaf(t1[e] * f1[k][e], mm, acc1[k]);
+        acc2[k] = fmaf(t2[e] * f2[k][e], mm, acc2[k]);
+        vs[k] += mm;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < RU; ++k) {
+    const float a = wave_sum(acc1[k]), a2 = wave_sum(acc2[k]);
+    if (lane == 0 && r0 + k < R) {
+      partial[((int64_t)b * R + r0 + k) * C + c] = a;
+      if (has2) partial[((int64_t)b * R + r0 + k) * C + c + 1] = a2;
+    }
+  }
+  if (c == 0) {   // wave-uniform: the overlap area, a count of {0,1} products (exact)
+#pragma unroll
+    for (int k = 0; k < RU; ++k) {
+      const float v = wave_sum(vs[k]);
+      if (lane == 0 && r0 + k < R) vsp[b * R + r0 + k] = v;
+    }
+  }
+}
+
+// One wave per (b, r): gs from the C channel partials (v_sum, the `zeros` flag and the normalisation; flags bit-exact).
+__global__ void __launch_bounds__(256) ctx_finalize_kernel(const float *__restrict__ partial, const float *__restrict__ vsp,
+                                                           float *__restrict__ gs, float *__restrict__ dscale, int BR, int C,
                                                            int variant, int normalize) {
   const int br = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (br >= BR) return;
-  const int b = br / R;
-  const float *vtb = vt + (int64_t)b * hw, *vrb = vr + (int64_t)br * hw;
-  float vs = 0.f, raw = 0.f;
-  for (int x = lane; x < hw; x += 64) vs += vtb[x] * vrb[x];
-  for (int k = lane; k < nblk; k += 64) raw += partial[(int64_t)br * nblk + k];
-  vs = wave_sum(vs);  // a count of {0,1} products: exact in fp32 up to 2^24 pixels
+  float raw = 0.f;
+  for (int k = lane; k < C; k += 64) raw += partial[(int64_t)br * C + k];
   raw = wave_sum(raw);
   if (lane == 0) {
+    const float vs = vsp[br];
     const bool zero = vs < 1e-4f;
     const float v_sum = zero ? vs + 1.f : vs;
     float g, ds;
@@ -282,79 +314,82 @@ __global__ void __launch_bounds__(256) ctx_finalize_kernel(const float *__restri
   }
 }
 
-// grid (xblocks, B), block (64,4); dynamic LDS = R*64*PX floats (softmax weights of the block's pixels).
-template <int PX>
-__global__ void __launch_bounds__(256) ctx_aggregate_kernel(const float *__restrict__ cf, const float *__restrict__ vt,
-                                                            const float *__restrict__ vr, const float *__restrict__ gs,
-                                                            float *__restrict__ p_in, float *__restrict__ c_mask,
-                                                            float *__restrict__ c_match, int C, int R, int hw, int variant,
-                                                            unsigned xblocks) {
-  extern __shared__ __attribute__((aligned(16))) float wts[];  // [R][64*PX]
-  constexpr int NPX = CTX_PXW * PX;
-  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = lin / xblocks, lane = threadIdx.x, wv = threadIdx.y, tid = wv * 64 + lane;
-  const int xb = (lin % xblocks) * NPX;
-  const float *vrb = vr + (int64_t)b * R * hw;
-  // phase 1: one thread per pixel of the block computes that pixel's softmax over the references
-  if (tid < NPX) {
-    const int x = xb + tid;
-    if (x < hw) {
-      const float vtx = vt[(int64_t)b * hw + x];
-      const float *g = gs + (int64_t)b * R;
-      float mx = -INFINITY;
-      for (int r = 0; r < R; ++r) mx = fmaxf(mx, g[r] * vrb[(int64_t)r * hw + x]);
-      float s = 0.f;
-      for (int r = 0; r < R; ++r) {
-        const float m = vrb[(int64_t)r * hw + x];
-        s += expf(g[r] * m - mx) * m;
-      }
-      if (s < 1e-4f) s += 1.f;
-      const float hole = variant == TCL_CTX_COMPLETE ? 1.f - vtx : 1.f;
-      float cm = 0.f;
-      for (int r = 0; r < R; ++r) {
-        const float m = vrb[(int64_t)r * hw + x];
-        const float wgt = (expf(g[r] * m - mx) * m / s) * hole;
-        wts[r * NPX + tid] = wgt;
-        c_match[((int64_t)b * R + r) * hw + x] = wgt;
-        cm += wgt * m;
-      }
-      cm = 1.f - cm;
-      c_mask[(int64_t)b * hw + x] = cm;
-      const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
-      p_in[((int64_t)b * (cch + 1) + cch) * hw + x] = cm;
-    } else {
-      for (int r = 0; r < R; ++r) wts[r * NPX + tid] = 0.f;
-    }
+// One thread per (b, pixel): softmax over the references -> c_match (B,R,hw), c_mask and the mask channel of p_in.
+__global__ void __launch_bounds__(256) ctx_weights_kernel(const float *__restrict__ vt, const float *__restrict__ vr,
+                                                          const float *__restrict__ gs, float *__restrict__ p_in,
+                                                          float *__restrict__ c_mask, float *__restrict__ c_match, int B, int C, int R,
+                                                          int hw, int variant) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * hw) return;
+  const int b = i / hw, x = i - b * hw;
+  const float *vrb = vr + (int64_t)b * R * hw + x, *g = gs + b * R;
+  const float vtx = vt[i];
+  float mx = -INFINITY;
+  for (int r = 0; r < R; ++r) mx = fmaxf(mx, g[r] * vrb[(int64_t)r * hw]);
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float m = vrb[(int64_t)r * hw];
+    s += expf(g[r] * m - mx) * m;
   }
-  __syncthreads();
-  // phase 2: lane = PX pixels, wave = channels wv, wv+4, ...
-  const int x = xb + lane * PX;
-  if (x >= hw) return;
-  float vtx[PX];
-  ldpx<PX>(vt + (int64_t)b * hw + x, vtx);
-  const float *cfb = cf + (int64_t)b * C * (R + 1) * hw + x;
-  const bool complete = variant == TCL_CTX_COMPLETE;
-  float *o = p_in + (int64_t)b * ((complete ? C : 2 * C) + 1) * hw + x;
-  for (int c = wv; c < C; c += 4) {
-    const float *fp = cfb + (int64_t)c * (R + 1) * hw;
-    float acc[PX], ft[PX];
+  if (s < 1e-4f) s += 1.f;
+  const float hole = variant == TCL_CTX_COMPLETE ? 1.f - vtx : 1.f;
+  float cm = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float m = vrb[(int64_t)r * hw];
+    const float wgt = (expf(g[r] * m - mx) * m / s) * hole;
+    c_match[((int64_t)b * R + r) * hw + x] = wgt;
+    cm += wgt * m;
+  }
+  cm = 1.f - cm;
+  c_mask[i] = cm;
+  const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
+  p_in[((int64_t)b * (cch + 1) + cch) * hw + x] = cm;
+}
+
+// One wave per (b, c), same slab walk: c_out[c,x] = sum_r f_r[c,x] w_r[x] (r ascending), written with the target
+// features into the concatenated decoder input.
+template <int RU, int PX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) ctx_aggregate_kernel(const float *cf, const float *vt, const float *c_match, float *p_in, int BC,
+                                                            int C, int hw, int variant, int R, int r0) {
+  // (no __restrict__ on purpose, see ctx_sim_kernel)
+  const int bc = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar, see ctx_sim_kernel
+  if (bc >= BC) return;
+  const int b = bc / C, c = bc - b * C;
+  const float *slab = cf + (int64_t)bc * (R + 1) * hw;
+  const float *vtb = vt + (int64_t)b * hw, *wb = c_match + (int64_t)b * R * hw;
+  const bool complete = variant == TCL_CTX_COMPLETE, last = r0 + RU >= R;
+  float *o = p_in + (int64_t)b * ((complete ? C : 2 * C) + 1) * hw;
+  float *oacc = o + (int64_t)(complete ? c : C + c) * hw;   // running sum over the passes (R > CTX_RMAX only)
+  int rr[RU];
+  float live[RU];
+#pragma unroll
+  for (int k = 0; k < RU; ++k) { rr[k] = min(r0 + k, R - 1); live[k] = r0 + k < R ? 1.f : 0.f; }
+  for (int x = lane * PX; x < hw; x += CTX_PXW * PX) {
+    float ft[PX], vtx[PX], fr[RU][PX], w[RU][PX], acc[PX];
+    ldpx<PX>(slab + x, ft);
+    ldpx<PX>(vtb + x, vtx);
 #pragma unroll
     for (int e = 0; e < PX; ++e) acc[e] = 0.f;
-    ldpx<PX>(fp, ft);
-    for (int r = 0; r < R; ++r) {
-      float fr[PX], wg[PX];
-      ldpx<PX>(fp + (int64_t)(r + 1) * hw, fr);
-      ldpx<PX>(wts + r * NPX + lane * PX, wg);
+    if (r0 > 0) ldpx<PX>(oacc + x, acc);
 #pragma unroll
-      for (int e = 0; e < PX; ++e) acc[e] += fr[e] * wg[e];
+    for (int k = 0; k < RU; ++k) {
+      ldpx<PX>(slab + (rr[k] + 1) * hw + x, fr[k]);
+      ldpx<PX>(wb + rr[k] * hw + x, w[k]);
     }
-    if (complete) {
+    TCL_LOADS_FIRST(2 * RU + 3);   // all loads of the step in flight before the first use
 #pragma unroll
-      for (int e = 0; e < PX; ++e) acc[e] = ft[e] * vtx[e] + acc[e];
-      stpx<PX>(o + (int64_t)c * hw, acc);
+    for (int e = 0; e < PX; ++e)
+#pragma unroll
+      for (int k = 0; k < RU; ++k) acc[e] += fr[k][e] * (w[k][e] * live[k]);
+    if (complete) {
+      if (last) {
+#pragma unroll
+        for (int e = 0; e < PX; ++e) acc[e] = ft[e] * vtx[e] + acc[e];
+      }
+      stpx<PX>(oacc + x, acc);
     } else {
-      stpx<PX>(o + (int64_t)c * hw, ft);
-      stpx<PX>(o + (int64_t)(C + c) * hw, acc);
+      if (r0 == 0) stpx<PX>(o + (int64_t)c * hw + x, ft);
+      stpx<PX>(oacc + x, acc);
     }
   }
 }
@@ -541,7 +576,7 @@ extern "C" int tcl_masked_softmax_bwd(const float *grad_out, const float *vec, c
 
 static int ctx_check(const char *fn, int64_t B, int64_t C, int64_t R, int64_t h, int64_t w, int variant) {
   TCL_REQUIRE(B > 0 && C > 0 && R > 0 && h > 0 && w > 0, TCL_ERR_SHAPE, "%s: bad shape B=%ld C=%ld R=%ld h=%ld w=%ld", fn, (long)B, (long)C, (long)R, (long)h, (long)w);
-  TCL_REQUIRE(B < 65536 && h * w < (1 << 24) && C * h * w < (1LL << 31) && R <= 64, TCL_ERR_SHAPE, "%s: shape out of range (R <= 64, B < 65536)", fn);
+  TCL_REQUIRE(B < 65536 && h * w < (1 << 24) && C * h * w < (1LL << 31) && R <= 64 && B * C < (1LL << 31), TCL_ERR_SHAPE, "%s: shape out of range (R <= 64, B < 65536)", fn);
   TCL_REQUIRE(variant >= TCL_CTX_DEFAULT && variant <= TCL_CTX_CM_MODULE, TCL_ERR_ARG, "%s: unknown variant %d", fn, variant);
   return TCL_OK;
 }
@@ -564,21 +599,38 @@ extern "C" int tcl_ctx_fwd(const float *c_feats, const float *v_t, const float *
   hipStream_t s = (hipStream_t)stream;
   const int hw = (int)(h * w);
   const CtxWs ws = ctx_ws(workspace, B, C, R, hw);
-  hipLaunchKernelGGL(resize_mask_kernel, dim3(stream_blocks(B * hw)), dim3(256), 0, s, v_t, ws.vt, B, (int)H, (int)W, (int)h, (int)w);
-  hipLaunchKernelGGL(resize_mask_kernel, dim3(stream_blocks(B * R * hw)), dim3(256), 0, s, v_aligned, ws.vr, B * R, (int)H, (int)W, (int)h, (int)w);
-  const int px = ctx_px(hw), xb = ctx_xblocks(hw);
-  if (px == 2)
-    hipLaunchKernelGGL(ctx_sim_kernel<2>, dim3((unsigned)(xb * ws.csplit * B)), dim3(64, 4), 0, s, c_feats, ws.vt, ws.vr, ws.partial, (int)C, (int)R, hw, ws.nblk, (unsigned)xb, (unsigned)ws.csplit);
-  else
-    hipLaunchKernelGGL(ctx_sim_kernel<1>, dim3((unsigned)(xb * ws.csplit * B)), dim3(64, 4), 0, s, c_feats, ws.vt, ws.vr, ws.partial, (int)C, (int)R, hw, ws.nblk, (unsigned)xb, (unsigned)ws.csplit);
-  hipLaunchKernelGGL(ctx_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, ws.vt, ws.vr, ws.partial, ws.gs, ws.dscale,
-                     (int)(B * R), (int)R, (int)C, hw, ws.nblk, variant, normalize);
-  if (px == 2)
-    hipLaunchKernelGGL(ctx_aggregate_kernel<2>, dim3((unsigned)(xb * B)), dim3(64, 4), (size_t)R * 128 * sizeof(float), s, c_feats,
-                       ws.vt, ws.vr, ws.gs, p_in, c_mask, c_match, (int)C, (int)R, hw, variant, (unsigned)xb);
-  else
-    hipLaunchKernelGGL(ctx_aggregate_kernel<1>, dim3((unsigned)(xb * B)), dim3(64, 4), (size_t)R * 64 * sizeof(float), s, c_feats,
-                       ws.vt, ws.vr, ws.gs, p_in, c_mask, c_match, (int)C, (int)R, hw, variant, (unsigned)xb);
+  if (hipMemsetAsync(ws.mbits, 0, (size_t)ws.passes * B * hw * sizeof(unsigned), s) != hipSuccess)
+    return set_error(TCL_ERR_LAUNCH, "tcl_ctx_fwd: hipMemsetAsync failed");
+  hipLaunchKernelGGL(ctx_resize_masks_kernel, dim3(stream_blocks(B * (R + 1) * hw)), dim3(256), 0, s, v_t, v_aligned, ws.vt, ws.vr, ws.mbits,
+                     (int)B, (int)R, (int)H, (int)W, (int)h, (int)w, ws.passes, ws.ru);
+  const int px = ctx_px(hw);
+  const int BC = (int)(B * C);
+  const dim3 grd((unsigned)cdiv(BC, 4)), blk(256);
+  const int ru = ws.ru;
+  int r0 = 0;
+#define TCL_CTX_SIM(RU, PX) hipLaunchKernelGGL((ctx_sim_kernel<RU, PX>), dim3((unsigned)cdiv(B * ((C + 1) / 2), 4)), blk, 0, s, c_feats, ws.mbits, ws.partial, ws.vsp, (int)B, (int)C, hw, (int)R, r0)
+#define TCL_CTX_AGG(RU, PX) hipLaunchKernelGGL((ctx_aggregate_kernel<RU, PX>), grd, blk, 0, s, c_feats, ws.vt, c_match, p_in, BC, (int)C, hw, variant, (int)R, r0)
+#define TCL_CTX_BY_R(WHAT)                                                                  \
+  do {                                                                                      \
+    switch (ru * 2 + (px - 1)) {                                                            \
+      case 2: WHAT(1, 1); break;   case 3: WHAT(1, 2); break;   case 4: WHAT(2, 1); break;   case 5: WHAT(2, 2); break;    \
+      case 6: WHAT(3, 1); break;   case 7: WHAT(3, 2); break;   case 8: WHAT(4, 1); break;   case 9: WHAT(4, 2); break;    \
+      case 10: WHAT(5, 1); break;  case 11: WHAT(5, 2); break;  case 12: WHAT(6, 1); break;  case 13: WHAT(6, 2); break;   \
+      case 14: WHAT(7, 1); break;  case 15: WHAT(7, 2); break;  case 16: WHAT(8, 1); break;  case 17: WHAT(8, 2); break;   \
+      case 18: WHAT(9, 1); break;  case 19: WHAT(9, 2); break;  case 20: WHAT(10, 1); break; case 21: WHAT(10, 2); break;  \
+      case 22: WHAT(11, 1); break; case 23: WHAT(11, 2); break; case 24: WHAT(12, 1); break; case 25: WHAT(12, 2); break;  \
+      case 26: WHAT(13, 1); break; case 27: WHAT(13, 2); break; case 28: WHAT(14, 1); break; case 29: WHAT(14, 2); break;  \
+      case 30: WHAT(15, 1); break; case 31: WHAT(15, 2); break; case 32: WHAT(16, 1); break; default: WHAT(16, 2); break;  \
+    }                                                                                       \
+  } while (0)
+  for (r0 = 0; r0 < R; r0 += ru) TCL_CTX_BY_R(TCL_CTX_SIM);
+  hipLaunchKernelGGL(ctx_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, ws.partial, ws.vsp, ws.gs, ws.dscale, (int)(B * R),
+                     (int)C, variant, normalize);
+  hipLaunchKernelGGL(ctx_weights_kernel, dim3((unsigned)cdiv(B * hw, 256)), dim3(256), 0, s, ws.vt, ws.vr, ws.gs, p_in, c_mask, c_match,
+                     (int)B, (int)C, (int)R, hw, variant);
+  for (r0 = 0; r0 < R; r0 += ru) TCL_CTX_BY_R(TCL_CTX_AGG);
+#undef TCL_CTX_SIM
+#undef TCL_CTX_AGG
   return check_launch("tcl_ctx_fwd");
 }
 
