@@ -53,39 +53,37 @@ __global__ void __launch_bounds__(256) dilate_cross3_kernel(const float *__restr
 }
 
 // ref_importance (B,3,R+1,H,W): planes = upsampled c_match with a middle plane inserted at R/2, hole border painted red.
+// 2-D grid (chunk of 256 pixels, b * (R+1) + j); straight-line: every load is unconditional (clamped neighbours /
+// clamped plane index), selected afterwards.
 __global__ void __launch_bounds__(256) ref_importance_kernel(const float *__restrict__ c_match, const float *__restrict__ v_t,
                                                              float *__restrict__ out, int B, int R, int h, int w, int H, int W,
-                                                             int middle_is_vt) {
-  const float sh = __fdiv_rn((float)h, (float)H), sw = __fdiv_rn((float)w, (float)W);
-  const int64_t HW = (int64_t)H * W, total = (int64_t)B * (R + 1) * HW;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t bj = i / HW;
-    const int pix = (int)(i - bj * HW), y = pix / W, x = pix - y * W;
-    const int b = (int)(bj / (R + 1)), j = (int)(bj - (int64_t)b * (R + 1));
-    const float *vt = v_t + (int64_t)b * HW;
-    // border = dilate(hole) - hole > 0 with hole = 1 - v_t; dilation of (1 - v) is 1 - erosion(v)
-    const float hole = 1.f - vt[pix];
-    float dil = hole;
-    if (y > 0) dil = fmaxf(dil, 1.f - vt[pix - W]);
-    if (y < H - 1) dil = fmaxf(dil, 1.f - vt[pix + W]);
-    if (x > 0) dil = fmaxf(dil, 1.f - vt[pix - 1]);
-    if (x < W - 1) dil = fmaxf(dil, 1.f - vt[pix + 1]);
-    const float border = (dil - hole) > 0.f ? 1.f : 0.f;
-    float val;
-    if (j == R / 2) {
-      val = middle_is_vt ? vt[pix] : 0.f;
-    } else {
-      const int r = j < R / 2 ? j : j - 1;
-      const float *p = c_match + ((int64_t)b * R + r) * h * w;
-      const LinTap ty = linear_tap(y, h, sh), tx = linear_tap(x, w, sw);
-      val = bilerp(p[ty.i0 * w + tx.i0], p[ty.i0 * w + tx.i1], p[ty.i1 * w + tx.i0], p[ty.i1 * w + tx.i1], tx, ty);
-    }
-    const float keep = val * (1.f - border);
-    float *o = out + ((int64_t)b * 3 * (R + 1) + j) * HW + pix;
-    o[0] = keep + border;
-    o[(int64_t)(R + 1) * HW] = keep;
-    o[(int64_t)2 * (R + 1) * HW] = keep;
-  }
+                                                             int middle_is_vt, float sh, float sw) {
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= HW) return;
+  const int bj = blockIdx.y, b = bj / (R + 1), j = bj - b * (R + 1);
+  const int y = pix / W, x = pix - y * W;
+  const float *vt = v_t + (int64_t)b * HW;
+  const bool middle = j == R / 2;
+  const int r = min(j < R / 2 ? j : j - 1, R - 1);
+  const float *p = c_match + ((int64_t)b * R + r) * h * w;
+  const LinTap ty = linear_tap(y, h, sh), tx = linear_tap(x, w, sw);
+  // loads
+  const float vc = vt[pix];
+  const float vn = vt[y > 0 ? pix - W : pix], vs = vt[y < H - 1 ? pix + W : pix];
+  const float vw = vt[x > 0 ? pix - 1 : pix], ve = vt[x < W - 1 ? pix + 1 : pix];
+  const float p00 = p[ty.i0 * w + tx.i0], p01 = p[ty.i0 * w + tx.i1], p10 = p[ty.i1 * w + tx.i0], p11 = p[ty.i1 * w + tx.i1];
+  // border = dilate(hole) - hole > 0 with hole = 1 - v_t; dilation of (1 - v) over the 3x3 cross
+  const float hole = 1.f - vc;
+  const float dil = fmaxf(fmaxf(fmaxf(hole, 1.f - vn), fmaxf(1.f - vs, 1.f - vw)), 1.f - ve);
+  const float border = (dil - hole) > 0.f ? 1.f : 0.f;
+  const float up = bilerp(p00, p01, p10, p11, tx, ty);
+  const float val = middle ? (middle_is_vt ? vc : 0.f) : up;
+  const float keep = val * (1.f - border);
+  float *o = out + ((int64_t)b * 3 * (R + 1) + j) * HW + pix;
+  o[0] = keep + border;
+  o[(int64_t)(R + 1) * HW] = keep;
+  o[(int64_t)2 * (R + 1) * HW] = keep;
 }
 
 // ------------------------------------------------------------------------------------------ A5 generic masked softmax
@@ -395,80 +393,121 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 }
 
 // ---- backward
-// Pass 1 (grid (ceil(hw/64), B), block 64 px x 4 channel groups, dynamic LDS = 4*R*64 floats):
-//   d_match[r][x] = sum_c g_out[c,x] f_r[c,x] - g_mask[x] vr_r[x]; softmax Jacobian per pixel; per-block partial of
-//   d_gs[b,r] = sum_x d_cos[r][x].
-__global__ void __launch_bounds__(256) ctx_bwd_match_kernel(const float *__restrict__ g_p_in, const float *__restrict__ g_c_mask,
-                                                            const float *__restrict__ cf, const float *__restrict__ vt,
-                                                            const float *__restrict__ vr, const float *__restrict__ gs,
-                                                            float *__restrict__ partial, int C, int R, int hw, int variant, int nbx) {
-  extern __shared__ __attribute__((aligned(16))) float dm[];  // [4][R][64]
-  const int b = blockIdx.y, px = threadIdx.x & 63, cg = threadIdx.x >> 6;
-  const int x = blockIdx.x * 64 + px;
-  const bool ok = x < hw;
+// Pass 1a: dpart[cs][b][r][x] = sum over the block's channels of g_out[c,x] f_r[c,x].
+//   grid (xblocks * csplit, B), block 256 = 4 waves: lane = PX pixels, wave = a strided channel subset, two channels per
+//   step, RU references per pass (all loads of a step unconditional and in flight together); the four waves are
+//   combined through LDS in a fixed order.
+template <int RU, int PX>
+__global__ void __launch_bounds__(256) ctx_bwd_dmatch_kernel(const float *g_p_in, const float *cf, float *dpart, int B, int C, int R, int hw,
+                                                             int variant, int xblocks, int csplit) {
+  constexpr int NPX = CTX_PXW * PX;
+  __shared__ float red[4][RU][NPX];
+  const int b = blockIdx.y, bxi = blockIdx.x % xblocks, cs = blockIdx.x / xblocks;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x0 = (bxi * CTX_PXW + lane) * PX;
+  const bool ok = x0 < hw;
+  const int x = ok ? x0 : 0;
   const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
   const int out_off = variant == TCL_CTX_COMPLETE ? 0 : C;   // channel offset of g_out inside g_p_in
-  const float *gpb = g_p_in + (int64_t)b * (cch + 1) * hw + x;
-  const float *cfb = cf + (int64_t)b * C * (R + 1) * hw + x;
-  for (int r0 = 0; r0 < R; r0 += CTX_RC) {
-    float acc[CTX_RC];
+  const float *gpb = g_p_in + ((int64_t)b * (cch + 1) + out_off) * hw + x;
+  const int64_t cstride = (int64_t)(R + 1) * hw;
+  const float *cfb = cf + (int64_t)b * C * cstride + x;
+  const int cstep = 4 * csplit, c0 = cs * 4 + wv;
+  for (int r0 = 0; r0 < R; r0 += RU) {
+    float acc[RU][PX];
+    int roff[RU];
 #pragma unroll
-    for (int k = 0; k < CTX_RC; ++k) acc[k] = 0.f;
-    if (ok)
-      for (int c = cg; c < C; c += 4) {
-        const float g = gpb[(int64_t)(out_off + c) * hw];
-        const float *fp = cfb + (int64_t)c * (R + 1) * hw;
+    for (int k = 0; k < RU; ++k) {
+      roff[k] = (min(r0 + k, R - 1) + 1) * hw;
 #pragma unroll
-        for (int k = 0; k < CTX_RC; ++k)
-          if (r0 + k < R) acc[k] += g * fp[(int64_t)(r0 + k + 1) * hw];
+      for (int e = 0; e < PX; ++e) acc[k][e] = 0.f;
+    }
+    for (int c = c0; c < C; c += 2 * cstep) {
+      const bool has2 = c + cstep < C;
+      const int c2 = has2 ? c + cstep : c;
+      const float *f1 = cfb + c * cstride, *f2 = cfb + c2 * cstride;
+      float g1[PX], g2[PX], r1[RU][PX], r2[RU][PX];
+      ldpx<PX>(gpb + (int64_t)c * hw, g1);
+      ldpx<PX>(gpb + (int64_t)c2 * hw, g2);
+#pragma unroll
+      for (int k = 0; k < RU; ++k) {
+        ldpx<PX>(f1 + roff[k], r1[k]);
+        ldpx<PX>(f2 + roff[k], r2[k]);
       }
+      TCL_LOADS_FIRST(2 * RU + 2);
+      const float w2 = has2 ? 1.f : 0.f;
 #pragma unroll
-    for (int k = 0; k < CTX_RC; ++k)
-      if (r0 + k < R) dm[(cg * R + r0 + k) * 64 + px] = acc[k];
+      for (int k = 0; k < RU; ++k)
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+          acc[k][e] += g1[e] * r1[k][e];
+          acc[k][e] += w2 * (g2[e] * r2[k][e]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RU; ++k) stpx<PX>(&red[wv][k][lane * PX], acc[k]);
+    __syncthreads();
+    for (int i = tid; i < RU * NPX; i += 256) {
+      const int k = i / NPX, px = i - k * NPX, xx = bxi * NPX + px;
+      if (r0 + k < R && xx < hw)
+        dpart[(((int64_t)cs * B + b) * R + r0 + k) * hw + xx] = (red[0][k][px] + red[1][k][px]) + (red[2][k][px] + red[3][k][px]);
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (cg != 0) return;
-  const float *vrb = vr + (int64_t)b * R * hw;
+}
+
+// Pass 1b: one thread per (b, pixel): d_match[r] = sum_cs dpart - g_mask vr_r, the softmax Jacobian (incl. the
+//   `sums < 1e-4` branch and the max's subgradient), and per-block partial sums of d_gs[b,r] = sum_x d_cos[r][x].
+//   grid (ceil(hw/256), B), dynamic LDS = R*256 floats.
+__global__ void __launch_bounds__(256) ctx_bwd_jacobian_kernel(const float *__restrict__ g_p_in, const float *__restrict__ g_c_mask,
+                                                               const float *__restrict__ dpart, const float *__restrict__ vt,
+                                                               const float *__restrict__ vr, const float *__restrict__ gs,
+                                                               float *__restrict__ partial, int B, int C, int R, int hw, int variant,
+                                                               int csplit, int nbx) {
+  extern __shared__ __attribute__((aligned(16))) float dm[];  // [R][256]
+  __shared__ float red[4];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int x0 = blockIdx.x * 256 + tid;
+  const bool ok = x0 < hw;
+  const int x = ok ? x0 : 0;
+  const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
+  const float *vrb = vr + (int64_t)b * R * hw + x;
   const float *g = gs + (int64_t)b * R;
-  float gmask = 0.f, hole = 1.f;
-  if (ok) {
-    gmask = gpb[(int64_t)cch * hw] + (g_c_mask ? g_c_mask[(int64_t)b * hw + x] : 0.f);
-    if (variant == TCL_CTX_COMPLETE) hole = 1.f - vt[(int64_t)b * hw + x];
-  }
+  const float gmask = g_p_in[((int64_t)b * (cch + 1) + cch) * hw + x] + (g_c_mask ? g_c_mask[(int64_t)b * hw + x] : 0.f);
+  const float hole = variant == TCL_CTX_COMPLETE ? 1.f - vt[(int64_t)b * hw + x] : 1.f;
   float mx = -INFINITY, s = 0.f, ge = 0.f, tot = 0.f;
   int am = 0;
-  if (ok) {
-    for (int r = 0; r < R; ++r) {
-      const float z = g[r] * vrb[(int64_t)r * hw + x];
-      if (z > mx) { mx = z; am = r; }
-    }
-    for (int r = 0; r < R; ++r) {
-      const float m = vrb[(int64_t)r * hw + x];
-      const float e = expf(g[r] * m - mx) * m;
-      const float d = (((dm[r * 64 + px] + dm[(R + r) * 64 + px]) + (dm[(2 * R + r) * 64 + px] + dm[(3 * R + r) * 64 + px])) - gmask * m) * hole;
-      dm[r * 64 + px] = d;   // d loss / d softmax_r
-      s += e;
-      ge += d * e;
-    }
+  for (int r = 0; r < R; ++r) {
+    const float z = g[r] * vrb[(int64_t)r * hw];
+    if (z > mx) { mx = z; am = r; }
+  }
+  for (int r = 0; r < R; ++r) {
+    const float m = vrb[(int64_t)r * hw];
+    const float e = expf(g[r] * m - mx) * m;
+    float d = 0.f;
+    for (int q = 0; q < csplit; ++q) d += dpart[(((int64_t)q * B + b) * R + r) * hw + x];
+    d = (d - gmask * m) * hole;
+    dm[r * 256 + tid] = d;   // d loss / d softmax_r
+    s += e;
+    ge += d * e;
   }
   const float sp = s < 1e-4f ? s + 1.f : s;
-  if (ok)
-    for (int r = 0; r < R; ++r) {
-      const float m = vrb[(int64_t)r * hw + x];
-      const float e = expf(g[r] * m - mx) * m;
-      tot += (dm[r * 64 + px] / sp - ge / (sp * sp)) * e;
-    }
   for (int r = 0; r < R; ++r) {
-    float d = 0.f;
-    if (ok) {
-      const float m = vrb[(int64_t)r * hw + x];
-      const float e = expf(g[r] * m - mx) * m;
-      d = (dm[r * 64 + px] / sp - ge / (sp * sp)) * e;
-      if (r == am) d -= tot;
-      d *= m;
-    }
-    d = wave_sum(d);  // cg == 0 is exactly wave 0
-    if (px == 0) partial[((int64_t)b * R + r) * nbx + blockIdx.x] = d;
+    const float m = vrb[(int64_t)r * hw];
+    const float e = expf(g[r] * m - mx) * m;
+    tot += (dm[r * 256 + tid] / sp - ge / (sp * sp)) * e;
+  }
+  for (int r = 0; r < R; ++r) {
+    const float m = vrb[(int64_t)r * hw];
+    const float e = expf(g[r] * m - mx) * m;
+    float d = (dm[r * 256 + tid] / sp - ge / (sp * sp)) * e;
+    if (r == am) d -= tot;
+    d = ok ? d * m : 0.f;
+    d = wave_sum(d);
+    if (lane == 0) red[wv] = d;
+    __syncthreads();
+    if (tid == 0) partial[((int64_t)b * R + r) * nbx + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
   }
 }
 
@@ -555,8 +594,10 @@ extern "C" int tcl_ref_importance(const float *c_match, const float *v_t, float 
                                   int64_t w, int64_t H, int64_t W, int middle_is_vt, void *stream) {
   TCL_REQUIRE(B > 0 && R > 0 && h > 0 && w > 0 && H > 0 && W > 0 && H * W < (1LL << 31), TCL_ERR_SHAPE, "tcl_ref_importance: bad shape");
   TCL_REQUIRE(c_match && v_t && ref_importance, TCL_ERR_ARG, "tcl_ref_importance: NULL pointer");
-  hipLaunchKernelGGL(ref_importance_kernel, dim3(stream_blocks(B * (R + 1) * H * W)), dim3(256), 0, (hipStream_t)stream, c_match, v_t,
-                     ref_importance, (int)B, (int)R, (int)h, (int)w, (int)H, (int)W, middle_is_vt);
+  TCL_REQUIRE(B * (R + 1) < 65536, TCL_ERR_SHAPE, "tcl_ref_importance: too many planes for one launch (%ld)", (long)(B * (R + 1)));
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;   // IEEE division, as __fdiv_rn
+  hipLaunchKernelGGL(ref_importance_kernel, dim3((unsigned)cdiv(H * W, 256), (unsigned)(B * (R + 1))), dim3(256), 0, (hipStream_t)stream,
+                     c_match, v_t, ref_importance, (int)B, (int)R, (int)h, (int)w, (int)H, (int)W, middle_is_vt, sh, sw);
   return check_launch("tcl_ref_importance");
 }
 
@@ -634,10 +675,19 @@ extern "C" int tcl_ctx_fwd(const float *c_feats, const float *v_t, const float *
   return check_launch("tcl_ctx_fwd");
 }
 
+static int ctx_bwd_csplit(int64_t B, int64_t C, int64_t hw) {
+  // blocks of the d_match kernel = B * xblocks * csplit: as many as are resident at once (8 per CU), never more
+  int64_t want = ((int64_t)kNumCU * 8) / (B * ctx_xblocks(hw));
+  const int64_t maxs = cdiv(C, 4 * 4);  // at least 4 channels per wave
+  if (want > maxs) want = maxs;
+  return (int)(want < 1 ? 1 : want);
+}
+static int ctx_bwd_ru(int64_t R) { return (int)cdiv(R, cdiv(R, CTX_RC)); }   // R = 10 -> two passes of 5
+
 extern "C" size_t tcl_ctx_bwd_workspace_bytes(int64_t B, int64_t C, int64_t R, int64_t h, int64_t w) {
-  (void)C;
-  if (B <= 0 || R <= 0 || h <= 0 || w <= 0) return 0;
-  return round_up((size_t)B * R * cdiv(h * w, 64) * 4, 256) + round_up((size_t)B * R * 4, 256);
+  if (B <= 0 || C <= 0 || R <= 0 || h <= 0 || w <= 0) return 0;
+  return round_up((size_t)B * R * cdiv(h * w, 256) * 4, 256) + round_up((size_t)B * R * 4, 256) +
+         round_up((size_t)ctx_bwd_csplit(B, C, h * w) * B * R * h * w * 4, 256);
 }
 
 extern "C" int tcl_ctx_bwd(const float *g_p_in, const float *g_c_mask, const float *c_feats, const float *c_match, const void *fwd_workspace,
@@ -652,12 +702,33 @@ extern "C" int tcl_ctx_bwd(const float *g_p_in, const float *g_c_mask, const flo
   TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
               "tcl_ctx_bwd: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
   hipStream_t s = (hipStream_t)stream;
-  const int hw = (int)(h * w), nbx = (int)cdiv(hw, 64);
+  const int hw = (int)(h * w), nbx = (int)cdiv(hw, 256);
   const CtxWs ws = ctx_ws(const_cast<void *>(fwd_workspace), B, C, R, hw);
   float *partial = (float *)workspace;
   float *coef = (float *)((char *)workspace + round_up((size_t)B * R * nbx * 4, 256));
-  hipLaunchKernelGGL(ctx_bwd_match_kernel, dim3(nbx, (unsigned)B), dim3(256), (size_t)4 * R * 64 * sizeof(float), s, g_p_in, g_c_mask, c_feats,
-                     ws.vt, ws.vr, ws.gs, partial, (int)C, (int)R, hw, variant, nbx);
+  float *dpart = (float *)((char *)coef + round_up((size_t)B * R * 4, 256));
+  const int csplit = ctx_bwd_csplit(B, C, hw), xb = ctx_xblocks(hw), px = ctx_px(hw), ru = ctx_bwd_ru(R);
+  const dim3 grd((unsigned)(xb * csplit), (unsigned)B), blk(256);
+#define TCL_CTX_DM(RU, PX) hipLaunchKernelGGL((ctx_bwd_dmatch_kernel<RU, PX>), grd, blk, 0, s, g_p_in, c_feats, dpart, (int)B, (int)C, (int)R, hw, variant, xb, csplit)
+#define TCL_CTX_DM_PX(RU)                \
+  do {                                   \
+    if (px == 2) TCL_CTX_DM(RU, 2);      \
+    else TCL_CTX_DM(RU, 1);              \
+  } while (0)
+  switch (ru) {
+    case 1: TCL_CTX_DM_PX(1); break;
+    case 2: TCL_CTX_DM_PX(2); break;
+    case 3: TCL_CTX_DM_PX(3); break;
+    case 4: TCL_CTX_DM_PX(4); break;
+    case 5: TCL_CTX_DM_PX(5); break;
+    case 6: TCL_CTX_DM_PX(6); break;
+    case 7: TCL_CTX_DM_PX(7); break;
+    default: TCL_CTX_DM_PX(8); break;
+  }
+#undef TCL_CTX_DM_PX
+#undef TCL_CTX_DM
+  hipLaunchKernelGGL(ctx_bwd_jacobian_kernel, dim3((unsigned)nbx, (unsigned)B), dim3(256), (size_t)R * 256 * sizeof(float), s, g_p_in, g_c_mask,
+                     dpart, ws.vt, ws.vr, ws.gs, partial, (int)B, (int)C, (int)R, hw, variant, csplit, nbx);
   hipLaunchKernelGGL(ctx_bwd_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, partial, ws.dscale, coef, (int)(B * R), nbx);
   if (ctx_px(hw) == 2)
     hipLaunchKernelGGL(ctx_bwd_feats_kernel<2>, dim3((unsigned)(ctx_xblocks(hw) * cdiv(C, 4) * B)), dim3(64, 4), 0, s, g_p_in, c_feats,
