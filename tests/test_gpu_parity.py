@@ -317,3 +317,96 @@ def test_errors_are_loud(mods):
         mods["corr"].compute_masked_4d_correlation(torch.zeros(1, 2, 2, 2, device=DEV), None, torch.zeros(1, 2, 2, device=DEV), None)
     with pytest.raises(TclError):
         mods["flow"].crop_flow(torch.zeros(1, 1, 4, 4, 2, device=DEV), (3, 3), (2, 2))
+
+
+# ------------------------------------------------------------------------------------------------ precision variants of A1
+def assert_close_bf16(got, ref, what=""):
+    """north_star's bar for the bf16-MFMA variant: 1e-2 (relative to the tensor's scale, plus 1e-2 relative)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    scale = max(1e-6, float(np.max(np.abs(ref))))
+    bad = np.abs(got - ref) > 1e-2 * scale + 1e-2 * np.abs(ref)
+    assert not bad.any(), "%s: %d/%d outside the bf16 bar" % (what, bad.sum(), bad.size)
+
+
+@pytest.mark.parametrize("B,C,F,H,W,masked", [
+    (2, 64, 2, 16, 16, True), (1, 512, 4, 16, 16, True), (2, 37, 3, 9, 7, True), (1, 256, 1, 64, 64, False), (1, 20, 2, 24, 20, True)])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_corr4d_precision_variants(mods, B, C, F, H, W, masked, precision):
+    """TCL_PREC_BF16X3 (hi/lo split, three bf16 MFMAs) must meet the fp32 bar; TCL_PREC_BF16 the 1e-2 bar."""
+    rng = np.random.default_rng(B * 1000 + C)
+    xt = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    xr = rng.standard_normal((B, C, F, H, W)).astype(np.float32)
+    vt = _masks(rng, (B, 1, H, W)) if masked else None
+    vr = _masks(rng, (B, 1, F, H, W)) if masked else None
+    cot = rng.standard_normal((B, F, H, W, H, W)).astype(np.float32)
+    txt, txr = T(xt, True), T(xr, True)
+    out = mods["corr"].compute_masked_4d_correlation(txt, T(vt), txr, T(vr), precision=precision)
+    gt, gr = torch.autograd.grad((out * T(cot)).sum(), [txt, txr])
+    oout = O.compute_masked_4d_correlation(xt, vt, xr, vr)
+    ogt, ogr = O.compute_masked_4d_correlation_bwd(xt, vt, xr, vr, cot)
+    check = assert_close if precision == "bf16x3" else assert_close_bf16
+    check(N(out), oout, what="corr4d fwd " + precision)
+    check(N(gt), ogt, what="corr4d g_x_t " + precision)
+    check(N(gr), ogr, what="corr4d g_x_r " + precision)
+
+
+@pytest.mark.parametrize("case", load_golden("corr4d"))
+def test_golden_corr4d_bf16x3(mods, case):
+    xt, xr = T(case["x_t"], True), T(case["x_r"], True)
+    out = mods["corr"].compute_masked_4d_correlation(xt, T(case.get("v_t")), xr, T(case.get("v_r")), precision="bf16x3")
+    assert_close(N(out), case["out"], what="corr4d fwd bf16x3")
+    gt, gr = torch.autograd.grad((out * T(case["cot"])).sum(), [xt, xr])
+    assert_close(N(gt), case["g_x_t"], what="corr4d g_x_t bf16x3")
+    assert_close(N(gr), case["g_x_r"], what="corr4d g_x_r bf16x3")
+
+
+# ------------------------------------------------------------------------------------------------ shape corners of the rewritten kernels
+@pytest.mark.parametrize("C,F,H,W", [(1, 2, 12, 20), (5, 1, 9, 31), (4, 3, 2, 2), (3, 2, 7, 1), (2, 1, 1, 5)])
+def test_warp_generic_channel_counts(C, F, H, W):
+    """align_set hard-codes 3 channels in the reference; the kernel's generic-C path (and W < 2) must agree with the same arithmetic."""
+    from master_thesis_amd import _lib, _ops
+    rng = np.random.default_rng(C * 100 + W)
+    B = 2
+    x = rng.random((B, C, F, H, W)).astype(np.float32)
+    v = _masks(rng, (B, 1, F, H, W), 0.7)
+    flow = (rng.random((B, F, H, W, 2)) * 2.6 - 1.3).astype(np.float32)
+    cot = rng.standard_normal((B, C, F, H, W)).astype(np.float32)
+    tx, tf = T(x, True), T(flow, True)
+    xa, va = _ops.WarpFn.apply(tx, T(v), tf.reshape(-1, H, W, 2), None, True, _lib.VMODE_NEAREST)
+    oxa, ova = O.align_set(x, v, flow)
+    assert_close(N(xa), oxa, what="warp x")
+    assert_exact(N(va), ova, what="warp v")
+    gx, gf = torch.autograd.grad((xa * T(cot)).sum(), [tx, tf])
+    ogx, ogf = O.align_set_bwd(x, v, flow, cot)
+    assert_close(N(gx), ogx, what="warp g_x")
+    assert_close(N(gf), ogf, what="warp g_flow")
+
+
+@pytest.mark.parametrize("B,C,R,h,w,variant", [
+    (2, 6, 20, 5, 7, "default"),      # R > 16: two passes of the slab kernels; odd hw (one pixel per lane)
+    (1, 7, 3, 6, 8, "complete"),      # odd channel count (a wave's second channel is missing)
+    (2, 5, 33, 4, 6, "cm_module"),    # three passes
+    (1, 1, 1, 3, 3, "default"),       # the smallest of everything
+    (1, 130, 9, 9, 14, "default"),    # more channels than one d_match block covers
+])
+def test_context_matching_shape_corners(mods, B, C, R, h, w, variant):
+    rng = np.random.default_rng(R * 10 + C)
+    H, W = 4 * h, 4 * w
+    cf = (0.3 * rng.standard_normal((B, C, R + 1, h, w))).astype(np.float32)
+    v_t = np.repeat(np.repeat(_masks(rng, (B, 1, h, w), 0.6), 4, axis=2), 4, axis=3)
+    v_al = np.repeat(np.repeat(_masks(rng, (B, 1, R, h, w), 0.7), 4, axis=3), 4, axis=4)
+    tcf = T(cf, True)
+    if variant == "default":
+        p_in, c_mask, _ = mods["cpn"].CPNContextMatchingDefault()(tcf, T(v_t), T(v_al), normalize=True)
+    elif variant == "complete":
+        p_in, c_mask, _ = mods["cpn"].CPNContextMatchingComplete()(tcf, T(v_t), T(v_al), normalize=True)
+    else:
+        p_in, c_mask = mods["cpo"].CM_Module()(tcf, T(v_t), T(v_al))
+    op, om, _ = O.context_matching(cf, v_t, v_al, True, variant)
+    assert_close(N(p_in), op, what="p_in")
+    assert_close(N(c_mask), om, what="c_mask")
+    cot1 = rng.standard_normal(op.shape).astype(np.float32)
+    cot2 = rng.standard_normal(om.shape).astype(np.float32)
+    (g,) = torch.autograd.grad((p_in * T(cot1)).sum() + (c_mask * T(cot2)).sum(), [tcf])
+    og = O.context_matching_bwd(cf, v_t, v_al, cot1, cot2, True, variant)
+    assert_close(N(g), og, rtol=1e-3, atol=1e-4, what="g_c_feats")
