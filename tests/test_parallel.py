@@ -1,0 +1,85 @@
+"""CPU tests of the multi-process layout (gloo, world_size 2): the shards cover the batch exactly once, running a hot-path
+function per shard and concatenating equals running it on the whole batch (no collective is needed on the data path), and
+the bucketed gradient all-reduce of the data-parallel training step reproduces the single-process gradient.  The stand-in
+for the HIP kernels here is the numpy oracle (the kernels themselves need a GPU; their parity is tests/test_gpu_parity.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from master_thesis_amd import parallel
+
+
+def test_partition_covers_everything_once():
+    for n in (0, 1, 7, 16, 513):
+        for ws in (1, 2, 3, 8):
+            spans = [parallel.partition(n, ws, r) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        parallel.partition(4, 2, 2)
+
+
+def test_shard_structures():
+    t = torch.arange(10).reshape(5, 2)
+    assert torch.equal(parallel.shard(t, 2, 0), t[:3]) and torch.equal(parallel.shard(t, 2, 1), t[3:])
+    d = parallel.shard({"a": t, "b": None}, 2, 1)
+    assert d["b"] is None and torch.equal(d["a"], t[3:])
+    assert torch.equal(parallel.shard([t], 5, 4)[0], t[4:])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world_size, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from oracle import tcl_oracle as O
+        # ---- data path: shard by sequence, no collective; gather only to compare
+        rng = np.random.default_rng(3)
+        B, C, F, S = 5, 8, 2, 4
+        xt = rng.standard_normal((B, C, S, S)).astype(np.float32)
+        xr = rng.standard_normal((B, C, F, S, S)).astype(np.float32)
+        vt = (rng.random((B, 1, S, S)) < 0.8).astype(np.float32)
+        vr = (rng.random((B, 1, F, S, S)) < 0.8).astype(np.float32)
+        full = O.compute_masked_4d_correlation(xt, vt, xr, vr)
+        mine = parallel.shard([torch.from_numpy(a) for a in (xt, vt, xr, vr)], world_size, rank)
+        local = torch.from_numpy(O.compute_masked_4d_correlation(*[t.numpy() for t in mine]))
+        got = parallel.gather_shards(local)
+        ok_data = bool(np.array_equal(got.numpy(), full))
+        # ---- training path: summed-and-averaged bucketed gradients == single-process gradient of the mean loss
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 3, 3, padding=1))
+        x = torch.randn(6, 3, 8, 8)
+        y = torch.randn(6, 3, 8, 8)
+        ref = [g.clone() for g in torch.autograd.grad(((net(x) - y) ** 2).mean(), list(net.parameters()))]
+        xs, ys = parallel.shard([x, y], world_size, rank)
+        net.zero_grad()
+        ((net(xs) - ys) ** 2).mean().backward()
+        buckets = parallel.GradientBuckets(net.parameters(), bucket_mb=0.0005)   # tiny buckets: several per model
+        buckets.reduce().wait()
+        ok_grad = len(buckets.buckets) > 1 and all(torch.allclose(p.grad, r, rtol=1e-5, atol=1e-6) for p, r in zip(net.parameters(), ref))
+        ret[rank] = (ok_data, ok_grad)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    world_size = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world_size, _free_port(), ret), nprocs=world_size, join=True)
+        assert dict(ret) == {0: (True, True), 1: (True, True)}
