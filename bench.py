@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,6 +155,25 @@ def main():
         el = float(t.item())
 
     pairs_per_step = w["B"] * w["F"] * world
+
+    # the other arithmetic variants of the same path, same workload, this rank only (reported beside the headline,
+    # never as `value`): bf16x3 = hi/lo split on bf16 MFMA, meets the fp32 bar; bf16 = plain bf16 operands, 1e-2 bar
+    variants = {}
+    if not args.no_variants:
+        for prec in ("bf16x3", "bf16"):
+            def vstep():
+                out = correlation.compute_masked_4d_correlation(xt, vt, xr, vr, precision=prec)
+                return torch.autograd.grad(out, [xt, xr], grad_outputs=cot)
+            for _ in range(2):
+                vstep()
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(10):
+                vstep()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - tv) / 10 * 1e3
+            variants[prec] = {"ms_per_step": round(ms, 4), "pairs_per_s_per_gpu": round(w["B"] * w["F"] / ms * 1e3, 1),
+                              "tolerance": "fp32 bar (1e-4)" if prec == "bf16x3" else "1e-2"}
     result = None
     if rank == 0:
         kms, kflops = time_dominant_kernel(w, dev)
@@ -181,6 +201,8 @@ def main():
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "ms_per_launch": round(kms, 4), "traffic": traffic},
         }
+        if variants:
+            result["variants"] = variants
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(w)
     if world > 1:
