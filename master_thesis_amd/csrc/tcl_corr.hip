@@ -24,60 +24,153 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------ normalise
 // x element (b,c,f,p) at ((b*C + c)*F + f)*P + p; v element (b,f,p); hat element ((b*F+f)*C + c)*P + p.
-// block = 64 pixels x 4 channel groups.
-__global__ void __launch_bounds__(256) corr_normalise_kernel(const float *__restrict__ x, const float *__restrict__ v,
+// block = 64 lanes x 4 channel groups; a lane owns PX (4 when P % 4 == 0, else 1) adjacent pixels and walks its
+// channels NU at a time: the NU loads of a step are unconditional (channel index clamped) and in flight together.
+constexpr int NU = 8;
+
+template <int PX> struct PxV { float v[PX]; };
+template <int PX> __device__ __forceinline__ PxV<PX> ldv(const float *p) {
+  PxV<PX> r;
+  if (PX == 4) { const f32x4 t = *reinterpret_cast<const f32x4 *>(p); r.v[0] = t[0]; r.v[1 % PX] = t[1]; r.v[2 % PX] = t[2]; r.v[3 % PX] = t[3]; }
+  else r.v[0] = p[0];
+  return r;
+}
+template <int PX> __device__ __forceinline__ void stv(float *p, const PxV<PX> &a) {
+  if (PX == 4) { f32x4 t = {a.v[0], a.v[1 % PX], a.v[2 % PX], a.v[3 % PX]}; *reinterpret_cast<f32x4 *>(p) = t; }
+  else p[0] = a.v[0];
+}
+
+template <int PX, int NCG>
+__global__ void __launch_bounds__(64 * NCG) corr_normalise_kernel(const float *__restrict__ x, const float *__restrict__ v,
                                                              float *__restrict__ hat, float *__restrict__ nrm, int C, int F, int P) {
   const int bf = blockIdx.y, b = bf / F, f = bf - b * F;
-  const int p = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int cg = threadIdx.x >> 6;
-  const bool ok = p < P;
-  const float m = (ok && v) ? v[(int64_t)bf * P + p] : 1.f;
+  const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int p0 = (blockIdx.x * 64 + lane) * PX;
+  const bool ok = p0 < P;
+  const int p = ok ? p0 : 0;
+  PxV<PX> m;
+#pragma unroll
+  for (int e = 0; e < PX; ++e) m.v[e] = 1.f;
+  if (v) m = ldv<PX>(v + (int64_t)bf * P + p);
   const float *xp = x + ((int64_t)b * C * F + f) * P + p;
-  float ss = 0.f;
-  if (ok)
-    for (int c = cg; c < C; c += 4) {
-      const float t = xp[(int64_t)c * F * P] * m;
-      ss += t * t;
+  const int64_t cs = (int64_t)F * P;
+  float ss[PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) ss[e] = 0.f;
+  for (int c0 = cg; c0 < C; c0 += NCG * NU) {
+    PxV<PX> t[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) t[u] = ldv<PX>(xp + min(c0 + NCG * u, C - 1) * cs);
+    TCL_LOADS_FIRST(NU);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const float live = c0 + NCG * u < C ? 1.f : 0.f;
+#pragma unroll
+      for (int e = 0; e < PX; ++e) { const float q = (t[u].v[e] * m.v[e]) * live; ss[e] += q * q; }
     }
-  __shared__ float red[4][64];
-  red[cg][threadIdx.x & 63] = ss;
+  }
+  __shared__ float red[NCG][64 * PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) red[cg][lane * PX + e] = ss[e];
   __syncthreads();
+  float den[PX];
+  PxV<PX> nn;
+#pragma unroll
+  for (int e = 0; e < PX; ++e) {
+    const int l = lane * PX + e;
+    float t4[4] = {0.f, 0.f, 0.f, 0.f};   // fixed summation order: four interleaved partial sums, then pairwise
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) t4[g & 3] += red[g][l];
+    nn.v[e] = sqrtf((t4[0] + t4[1]) + (t4[2] + t4[3]));
+    den[e] = nn.v[e] + kNormEps;
+  }
   if (!ok) return;
-  const int l = threadIdx.x & 63;
-  const float n = sqrtf((red[0][l] + red[1][l]) + (red[2][l] + red[3][l]));
-  const float den = n + kNormEps;
   float *hp = hat + (int64_t)bf * C * P + p;
-  for (int c = cg; c < C; c += 4) hp[(int64_t)c * P] = (xp[(int64_t)c * F * P] * m) / den;
-  if (cg == 0) nrm[(int64_t)bf * P + p] = n;
+  for (int c0 = cg; c0 < C; c0 += NCG * NU) {
+    PxV<PX> t[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) t[u] = ldv<PX>(xp + min(c0 + NCG * u, C - 1) * cs);
+    TCL_LOADS_FIRST(NU);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+      for (int e = 0; e < PX; ++e) t[u].v[e] = (t[u].v[e] * m.v[e]) / den[e];
+      if (c0 + NCG * u < C) stv<PX>(hp + (int64_t)(c0 + NCG * u) * P, t[u]);
+    }
+  }
+  if (cg == 0) stv<PX>(nrm + (int64_t)bf * P + p, nn);
 }
 
 // Jacobian of the normalisation: g_x = v * (d_hat/(n+eps) - t * <d_hat,t> / ((n+eps)^2 n)),  0-norm -> first term only.
-__global__ void __launch_bounds__(256) corr_normalise_bwd_kernel(const float *__restrict__ x, const float *__restrict__ v,
+template <int PX, int NCG>
+__global__ void __launch_bounds__(64 * NCG) corr_normalise_bwd_kernel(const float *__restrict__ x, const float *__restrict__ v,
                                                                  const float *__restrict__ dhat, const float *__restrict__ nrm,
                                                                  float *__restrict__ gx, int C, int F, int P) {
   const int bf = blockIdx.y, b = bf / F, f = bf - b * F;
-  const int p = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int cg = threadIdx.x >> 6;
-  const bool ok = p < P;
-  const float m = (ok && v) ? v[(int64_t)bf * P + p] : 1.f;
+  const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int p0 = (blockIdx.x * 64 + lane) * PX;
+  const bool ok = p0 < P;
+  const int p = ok ? p0 : 0;
+  PxV<PX> m;
+#pragma unroll
+  for (int e = 0; e < PX; ++e) m.v[e] = 1.f;
+  if (v) m = ldv<PX>(v + (int64_t)bf * P + p);
   const float *xp = x + ((int64_t)b * C * F + f) * P + p;
   const float *dp = dhat + (int64_t)bf * C * P + p;
-  float dot = 0.f;
-  if (ok)
-    for (int c = cg; c < C; c += 4) dot += dp[(int64_t)c * P] * (xp[(int64_t)c * F * P] * m);
-  __shared__ float red[4][64];
-  red[cg][threadIdx.x & 63] = dot;
+  const int64_t cs = (int64_t)F * P;
+  float dot[PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) dot[e] = 0.f;
+  constexpr int NH = NU / 2;
+  for (int c0 = cg; c0 < C; c0 += NCG * NH) {
+    PxV<PX> t[NH], d[NH];
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const int c = min(c0 + NCG * u, C - 1);
+      t[u] = ldv<PX>(xp + c * cs);
+      d[u] = ldv<PX>(dp + (int64_t)c * P);
+    }
+    TCL_LOADS_FIRST(NU);
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const float live = c0 + NCG * u < C ? 1.f : 0.f;
+#pragma unroll
+      for (int e = 0; e < PX; ++e) dot[e] += (d[u].v[e] * (t[u].v[e] * m.v[e])) * live;
+    }
+  }
+  __shared__ float red[NCG][64 * PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) red[cg][lane * PX + e] = dot[e];
   __syncthreads();
+  const PxV<PX> n = ldv<PX>(nrm + (int64_t)bf * P + p);
+  float ne[PX], k[PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) {
+    const int l = lane * PX + e;
+    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) t4[g & 3] += red[g][l];
+    const float dt = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    ne[e] = n.v[e] + kNormEps;
+    k[e] = n.v[e] > 0.f ? dt / (ne[e] * ne[e] * n.v[e]) : 0.f;
+  }
   if (!ok) return;
-  const int l = threadIdx.x & 63;
-  dot = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-  const float n = nrm[(int64_t)bf * P + p];
-  const float ne = n + kNormEps;
-  const float k = n > 0.f ? dot / (ne * ne * n) : 0.f;
   float *gp = gx + ((int64_t)b * C * F + f) * P + p;
-  for (int c = cg; c < C; c += 4) {
-    const float t = xp[(int64_t)c * F * P] * m;
-    gp[(int64_t)c * F * P] = (dp[(int64_t)c * P] / ne - t * k) * m;
+  for (int c0 = cg; c0 < C; c0 += NCG * NH) {
+    PxV<PX> t[NH], d[NH];
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const int c = min(c0 + NCG * u, C - 1);
+      t[u] = ldv<PX>(xp + c * cs);
+      d[u] = ldv<PX>(dp + (int64_t)c * P);
+    }
+    TCL_LOADS_FIRST(NU);
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+#pragma unroll
+      for (int e = 0; e < PX; ++e) d[u].v[e] = (d[u].v[e] / ne[e] - (t[u].v[e] * m.v[e]) * k[e]) * m.v[e];
+      if (c0 + NCG * u < C) stv<PX>(gp + (c0 + NCG * u) * cs, d[u]);
+    }
   }
 }
 
@@ -636,6 +729,29 @@ extern "C" size_t tcl_corr4d_fwd_workspace_bytes(int64_t B, int64_t C, int64_t F
   return corr_ws(nullptr, B, C, F, P).bytes;
 }
 
+
+// launches the (forward or backward) normalisation with 4 pixels per lane when every row is 16-byte aligned
+static bool norm_vec_ok(int64_t P, const void *a, const void *b, const void *c, const void *d, const void *e) {
+  return P % 4 == 0 && aligned(a, 16) && aligned(b, 16) && aligned(c, 16) && aligned(d, 16) && aligned(e, 16);
+}
+static void launch_normalise(hipStream_t s, const float *x, const float *v, float *hat, float *nrm, int64_t BF, int C, int F, int64_t P) {
+  if (!norm_vec_ok(P, x, v, hat, nrm, nullptr))
+    hipLaunchKernelGGL((corr_normalise_kernel<1, 4>), dim3((unsigned)cdiv(P, 64), (unsigned)BF), dim3(256), 0, s, x, v, hat, nrm, C, F, (int)P);
+  else if (cdiv(P, 256) * BF >= 4 * kNumCU || C < 128)   // enough blocks: 4 waves each; else 16 waves share the channels
+    hipLaunchKernelGGL((corr_normalise_kernel<4, 4>), dim3((unsigned)cdiv(P, 256), (unsigned)BF), dim3(256), 0, s, x, v, hat, nrm, C, F, (int)P);
+  else
+    hipLaunchKernelGGL((corr_normalise_kernel<4, 16>), dim3((unsigned)cdiv(P, 256), (unsigned)BF), dim3(1024), 0, s, x, v, hat, nrm, C, F, (int)P);
+}
+static void launch_normalise_bwd(hipStream_t s, const float *x, const float *v, const float *dhat, const float *nrm, float *gx, int64_t BF,
+                                 int C, int F, int64_t P) {
+  if (!norm_vec_ok(P, x, v, dhat, nrm, gx))
+    hipLaunchKernelGGL((corr_normalise_bwd_kernel<1, 4>), dim3((unsigned)cdiv(P, 64), (unsigned)BF), dim3(256), 0, s, x, v, dhat, nrm, gx, C, F, (int)P);
+  else if (cdiv(P, 256) * BF >= 4 * kNumCU || C < 128)
+    hipLaunchKernelGGL((corr_normalise_bwd_kernel<4, 4>), dim3((unsigned)cdiv(P, 256), (unsigned)BF), dim3(256), 0, s, x, v, dhat, nrm, gx, C, F, (int)P);
+  else
+    hipLaunchKernelGGL((corr_normalise_bwd_kernel<4, 16>), dim3((unsigned)cdiv(P, 256), (unsigned)BF), dim3(1024), 0, s, x, v, dhat, nrm, gx, C, F, (int)P);
+}
+
 static int corr_check(const char *fn, int64_t B, int64_t C, int64_t F, int64_t P, int precision) {
   TCL_REQUIRE(B > 0 && C > 0 && F > 0 && P > 0, TCL_ERR_SHAPE, "%s: bad shape B=%ld C=%ld F=%ld P=%ld", fn, (long)B, (long)C, (long)F, (long)P);
   TCL_REQUIRE(B * F < 65536 && P < (1 << 24) && C < (1 << 20), TCL_ERR_SHAPE, "%s: shape out of range", fn);
@@ -655,9 +771,8 @@ extern "C" int tcl_corr4d_fwd(const float *x_t, const float *v_t, const float *x
               "tcl_corr4d_fwd: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
   hipStream_t s = (hipStream_t)stream;
   const CorrWs w = corr_ws(workspace, B, C, F, P);
-  const dim3 blk(256);
-  hipLaunchKernelGGL(corr_normalise_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)B), blk, 0, s, x_t, v_t, w.a_hat, w.n_t, (int)C, 1, (int)P);
-  hipLaunchKernelGGL(corr_normalise_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)(B * F)), blk, 0, s, x_r, v_r, w.r_hat, w.n_r, (int)C, (int)F, (int)P);
+  launch_normalise(s, x_t, v_t, w.a_hat, w.n_t, B, (int)C, 1, P);
+  launch_normalise(s, x_r, v_r, w.r_hat, w.n_r, B * F, (int)C, (int)F, P);
   rc = check_launch("tcl_corr4d_fwd(normalise)");
   if (rc) return rc;
   return tcl_corr4d_contract(workspace, out, B, C, F, P, precision, stream);
@@ -700,8 +815,8 @@ extern "C" int tcl_corr4d_argmax_flow(const float *x_t, const float *v_t, const 
   const CorrWs w = corr_ws(workspace, B, C, F, P);
   float2 *part = (float2 *)((char *)workspace + w.bytes);
   const dim3 blk(256);
-  hipLaunchKernelGGL(corr_normalise_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)B), blk, 0, s, x_t, v_t, w.a_hat, w.n_t, (int)C, 1, (int)P);
-  hipLaunchKernelGGL(corr_normalise_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)(B * F)), blk, 0, s, x_r, v_r, w.r_hat, w.n_r, (int)C, (int)F, (int)P);
+  launch_normalise(s, x_t, v_t, w.a_hat, w.n_t, B, (int)C, 1, P);
+  launch_normalise(s, x_r, v_r, w.r_hat, w.n_r, B * F, (int)C, (int)F, P);
   rc = check_launch("tcl_corr4d_argmax_flow(normalise)");
   if (rc) return rc;
   GemmArgs g{};
@@ -740,7 +855,6 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
   const CorrWs w = corr_ws(const_cast<void *>(fwd_workspace), B, C, F, P);
   float *d_a = (float *)workspace;
   float *d_r = (float *)((char *)workspace + round_up((size_t)B * C * P * 4, 256));
-  const dim3 blk(256);
   const int nsplit = precision == TCL_PREC_BF16X3 ? 2 : 1;
   if (g_x_t) {
     // d_a^[b][c][p] = sum_f sum_q r^[b,f][c][q] G[b,f][p][q]      (M = C, N = P, K = P per reference frame)
@@ -753,7 +867,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, true>(g, nsplit, s, "tcl_corr4d_bwd(d_a bf16 gemm)");
     else rc = launch_gemm<256, 128, 4, 2, true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
     if (rc) return rc;
-    hipLaunchKernelGGL(corr_normalise_bwd_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)B), blk, 0, s, x_t, v_t, d_a, w.n_t, g_x_t, (int)C, 1, (int)P);
+    launch_normalise_bwd(s, x_t, v_t, d_a, w.n_t, g_x_t, B, (int)C, 1, P);
     rc = check_launch("tcl_corr4d_bwd(normalise bwd, target)");
     if (rc) return rc;
   }
@@ -768,7 +882,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, false>(g, nsplit, s, "tcl_corr4d_bwd(d_r bf16 gemm)");
     else rc = launch_gemm<256, 128, 4, 2, true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
     if (rc) return rc;
-    hipLaunchKernelGGL(corr_normalise_bwd_kernel, dim3((unsigned)cdiv(P, 64), (unsigned)(B * F)), blk, 0, s, x_r, v_r, d_r, w.n_r, g_x_r, (int)C, (int)F, (int)P);
+    launch_normalise_bwd(s, x_r, v_r, d_r, w.n_r, g_x_r, B * F, (int)C, (int)F, P);
     rc = check_launch("tcl_corr4d_bwd(normalise bwd, refs)");
   }
   return rc;
