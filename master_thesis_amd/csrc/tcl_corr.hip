@@ -187,6 +187,7 @@ struct GemmArgs {
   int a_bdiv;             // A batch index = z / a_bdiv
   int nbatch;
   int tiles_m, tiles_n;
+  int d_vec;              // D rows are 16-byte aligned: the store epilogue writes float4
 };
 
 constexpr int BK = 32;
@@ -327,7 +328,8 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            acc[i][j] = EPI == EPI_STORE ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0)   // transposed tile, see the epilogue
+                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -374,16 +376,27 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
     }
     return;
   }
+  // The tiles were accumulated transposed (B fragment as the MFMA's A operand): a lane holds ONE row m of D and, in
+  // each register quad, four consecutive columns n -> one 16-byte store per quad instead of four 4-byte stores.
   float *Db = g.D + (int64_t)z * g.d_bs;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn0 + j * 32 + lr;
+      const int m = m0 + wm0 + i * 32 + lr;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < g.M && n < g.N) Db[(int64_t)m * g.d_ld + n] = acc[i][j][r];
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn0 + j * 32 + 8 * q + 4 * lh;
+        float *dst = Db + (int64_t)m * g.d_ld + n;
+        if (m < g.M) {
+          if (g.d_vec && n + 3 < g.N) {
+            const f32x4 val = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *reinterpret_cast<f32x4 *>(dst) = val;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < g.N) dst[e] = acc[i][j][4 * q + e];
+          }
+        }
       }
     }
 }
@@ -392,6 +405,7 @@ template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI = EPI_ST
 static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
   g.tiles_m = (int)cdiv(g.M, BM);
   g.tiles_n = (int)cdiv(g.N, BN);
+  g.d_vec = aligned(g.D, 16) && g.d_ld % 4 == 0 && g.d_bs % 4 == 0;
   const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
   TCL_REQUIRE(blocks > 0 && blocks < (1LL << 31), TCL_ERR_SHAPE, "%s: grid of %ld blocks", what, (long)blocks);
   // float4 staging needs 16-byte aligned rows along each operand's contiguous axis
@@ -571,25 +585,36 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if (NS == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);   // transposed tiles, see the epilogue
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
         }
     }
     __syncthreads();
   }
 
+  // The tiles were accumulated transposed (B fragment as the MFMA's A operand): a lane holds ONE row m of D and, in
+  // each register quad, four consecutive columns n -> one 16-byte store per quad instead of four 4-byte stores.
   float *Db = g.D + (int64_t)z * g.d_bs;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn0 + j * 32 + lr;
+      const int m = m0 + wm0 + i * 32 + lr;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < g.M && n < g.N) Db[(int64_t)m * g.d_ld + n] = acc[i][j][r];
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn0 + j * 32 + 8 * q + 4 * lh;
+        float *dst = Db + (int64_t)m * g.d_ld + n;
+        if (m < g.M) {
+          if (g.d_vec && n + 3 < g.N) {
+            const f32x4 val = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *reinterpret_cast<f32x4 *>(dst) = val;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < g.N) dst[e] = acc[i][j][4 * q + e];
+          }
+        }
       }
     }
 }
@@ -603,6 +628,7 @@ template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
 static int launch_gemm_bf16(GemmArgs g, int nsplit, hipStream_t s, const char *what) {
   g.tiles_m = (int)cdiv(g.M, BM);
   g.tiles_n = (int)cdiv(g.N, BN);
+  g.d_vec = aligned(g.D, 16) && g.d_ld % 4 == 0 && g.d_bs % 4 == 0;
   const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
   TCL_REQUIRE(blocks > 0 && blocks < (1LL << 31), TCL_ERR_SHAPE, "%s: grid of %ld blocks", what, (long)blocks);
   const bool vec = gemm_vec_ok(g, A_KC, B_KC);
