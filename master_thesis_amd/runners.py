@@ -1,0 +1,70 @@
+"""The static step functions of the reference's alignment runner on top of the HIP ops.
+
+Mirrors `ThesisAlignmentRunner.train_step_propagate` (thesis_dfpn/runner.py:104-151) and `infer_step_propagate`
+(thesis_dfpn/runner.py:153-159): same arguments, same returned tuple.  `model` is any callable with the alignment
+network's interface, `model(x_target, m_target, x_refs, m_refs) -> (corr, flow_16, flow_64, flow_256)`
+(models/thesis_alignment.py:177-207); the conv stacks behind it are not part of this package.  Everything after the model
+call is the hot path: six `align_set` warps at 16 / 64 / 256 px, two nearest `resize_flow`s and the `v_map`s.
+`resize_set` (utils/transforms.py:7-23) is caller-side glue on stock `F.interpolate`, kept as in the reference.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _ops
+from .utils import flow as flow_ops
+
+
+def resize_set(x, v, y, size):
+    """(x, v, y) at size x size: bilinear for the frames, nearest for the visibility maps.  utils/transforms.py:7-23."""
+    b, c, f, h, w = x.size()
+    x_new = F.interpolate(x.transpose(1, 2).reshape(-1, c, h, w), (size, size), mode='bilinear').reshape(b, f, c, size, size).transpose(1, 2)
+    v_new = F.interpolate(v.transpose(1, 2).reshape(-1, 1, h, w), (size, size)).reshape(b, f, 1, size, size).transpose(1, 2)
+    y_new = F.interpolate(y.transpose(1, 2).reshape(-1, c, h, w), (size, size), mode='bilinear').reshape(b, f, c, size, size).transpose(1, 2)
+    return x_new, v_new, y_new
+
+
+def train_step_propagate(model, x, m, y, flow_gt, flows_use, t, r_list):
+    """thesis_dfpn/runner.py:104-151.  x, y (B,3,F,H,W), m (B,1,F,H,W), flow_gt (B,F,H,W,2), flows_use (B,) bool."""
+    corr, flow_16, flow_64, flow_256 = model(x[:, :, t], m[:, :, t], x[:, :, r_list], m[:, :, r_list])
+
+    x_16, v_16, y_16 = resize_set(x, 1 - m, y, 16)
+    x_64, v_64, y_64 = resize_set(x, 1 - m, y, 64)
+    x_256, v_256, y_256 = x, 1 - m, y
+
+    flow_256_gt = flow_gt[:, r_list]
+    flow_16_gt = flow_ops.resize_flow(flow_256_gt, (16, 16))
+    flow_64_gt = flow_ops.resize_flow(flow_256_gt, (64, 64))
+
+    x_16_aligned_gt, v_16_aligned_gt = flow_ops.align_set(x_16[:, :, r_list], v_16[:, :, r_list], flow_16_gt)
+    x_64_aligned_gt, v_64_aligned_gt = flow_ops.align_set(x_64[:, :, r_list], v_64[:, :, r_list], flow_64_gt)
+    x_256_aligned_gt, v_256_aligned_gt = flow_ops.align_set(x_256[:, :, r_list], v_256[:, :, r_list], flow_256_gt)
+
+    # target v_maps: only for the items whose ground-truth flow is usable, zero elsewhere
+    use = flows_use.view(-1, 1, 1, 1, 1).to(v_64.dtype)
+    v_map_64_gt = _ops.vmap(v_64_aligned_gt, v_64[:, :, t]) * use
+    v_map_256_gt = _ops.vmap(v_256_aligned_gt, v_256[:, :, t]) * use
+
+    x_16_aligned, v_16_aligned = flow_ops.align_set(x_16[:, :, r_list], v_16[:, :, r_list], flow_16)
+    x_64_aligned, v_64_aligned = flow_ops.align_set(x_64[:, :, r_list], v_64[:, :, r_list], flow_64)
+    x_256_aligned, v_256_aligned = flow_ops.align_set(x_256[:, :, r_list], v_256[:, :, r_list], flow_256)
+
+    v_map_64 = _ops.vmap(v_64_aligned, v_64[:, :, t])
+    v_map_256 = _ops.vmap(v_256_aligned, v_256[:, :, t])
+
+    xs, vs, ys = (x_16, x_64, x_256), (v_16, v_64, v_256), (y_16, y_64, y_256)
+    xs_aligned = (x_16_aligned, x_64_aligned, x_256_aligned)
+    xs_aligned_gt = (x_16_aligned_gt, x_64_aligned_gt, x_256_aligned_gt)
+    vs_aligned = (v_16_aligned, v_64_aligned, v_256_aligned)
+    vs_aligned_gt = (v_16_aligned_gt, v_64_aligned_gt, v_256_aligned_gt)
+    flows, flows_gt = (flow_16, flow_64, flow_256), (flow_16_gt, flow_64_gt, flow_256_gt)
+    v_maps, v_maps_gt = (v_map_64, v_map_256), (v_map_64_gt, v_map_256_gt)
+    return corr, xs, vs, ys, xs_aligned, xs_aligned_gt, vs_aligned, vs_aligned_gt, flows, flows_gt, flows_use, v_maps, v_maps_gt
+
+
+def infer_step_propagate(model, x_target, m_target, x_ref, m_ref):
+    """thesis_dfpn/runner.py:153-159: the unit the FF / IP / CP sequence schedulers call once per (target, reference) pair."""
+    with torch.no_grad():
+        *_, flow_256 = model(x_target, m_target, x_ref, m_ref)
+    x_ref_aligned, v_ref_aligned = flow_ops.align_set(x_ref, 1 - m_ref, flow_256)
+    v_map = _ops.vmap(v_ref_aligned, 1 - m_target)
+    return x_ref_aligned, v_ref_aligned, v_map

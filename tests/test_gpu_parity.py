@@ -410,3 +410,66 @@ def test_context_matching_shape_corners(mods, B, C, R, h, w, variant):
     (g,) = torch.autograd.grad((p_in * T(cot1)).sum() + (c_mask * T(cot2)).sum(), [tcf])
     og = O.context_matching_bwd(cf, v_t, v_al, cot1, cot2, True, variant)
     assert_close(N(g), og, rtol=1e-3, atol=1e-4, what="g_c_feats")
+
+
+# ------------------------------------------------------------------------------------------------ callers of the path
+def _standin_model(flows):
+    """A callable with the alignment network's interface that returns fixed flows (the conv stacks are out of scope)."""
+    def model(x_t, m_t, x_r, m_r):
+        return (None,) + tuple(flows)
+    return model
+
+
+def test_runner_step_functions_vs_oracle():
+    """train_step_propagate / infer_step_propagate of thesis_dfpn/runner.py:104-159 on the HIP ops == the same composition of
+    the oracle's ops (resize_set is stock F.interpolate on both sides)."""
+    import torch.nn.functional as F
+    from master_thesis_amd import runners
+    rng = np.random.default_rng(77)
+    B, Fr, H, W = 2, 3, 256, 256
+    t, r_list = 1, [0, 2]
+    x = rng.random((B, 3, Fr, H, W)).astype(np.float32)
+    y = rng.random((B, 3, Fr, H, W)).astype(np.float32)
+    m = 1 - np.repeat(np.repeat(_masks(rng, (B, 1, Fr, H // 16, W // 16), 0.8), 16, axis=3), 16, axis=4)
+    def ident(s):
+        return np.stack(np.meshgrid(np.linspace(-1, 1, s), np.linspace(-1, 1, s)), axis=-1).astype(np.float32)
+    flow_gt = (ident(256)[None, None] * 1.05 + 0.1 * (rng.random((B, Fr, 1, 1, 2)) - 0.5)).astype(np.float32)
+    flows = [(ident(s)[None, None] * 0.97 + 0.08 * (rng.random((B, len(r_list), 1, 1, 2)) - 0.5)).astype(np.float32) for s in (16, 64, 256)]
+    flows_use = np.array([True, False])
+    tflows = [T(f, True) for f in flows]
+    out = runners.train_step_propagate(_standin_model(tflows), T(x), T(m), T(y), T(flow_gt), torch.from_numpy(flows_use).to(DEV), t, r_list)
+    corr, xs, vs, ys, xs_al, xs_al_gt, vs_al, vs_al_gt, fl, fl_gt, _, v_maps, v_maps_gt = out
+    # oracle composition on the CPU
+    cx, cm, cy = torch.from_numpy(x), torch.from_numpy(m), torch.from_numpy(y)
+    sets = [runners.resize_set(cx, 1 - cm, cy, 16), runners.resize_set(cx, 1 - cm, cy, 64), (cx, 1 - cm, cy)]
+    gt256 = flow_gt[:, r_list]
+    o_gt = [O.resize_flow(gt256, (16, 16)), O.resize_flow(gt256, (64, 64)), gt256]
+    for k in range(3):
+        ox, ov = sets[k][0].numpy(), sets[k][1].numpy()
+        assert_close(N(xs[k]), ox, what="resize_set x")
+        assert_exact(N(fl_gt[k]), o_gt[k], what="flow_gt scale %d" % k)
+        oxa, ova = O.align_set(ox[:, :, r_list], ov[:, :, r_list], flows[k])
+        assert_close(N(xs_al[k]), oxa, rtol=1e-4, atol=2e-5, what="x_aligned scale %d" % k)
+        mism = (N(vs_al[k]) != ova).mean()
+        assert mism < 1e-4, "v_aligned scale %d: %.2e mismatching (interpolated inputs differ in the last bit)" % (k, mism)
+        oxg, ovg = O.align_set(ox[:, :, r_list], ov[:, :, r_list], o_gt[k])
+        assert_close(N(xs_al_gt[k]), oxg, rtol=1e-4, atol=2e-5, what="x_aligned_gt scale %d" % k)
+        if k > 0:
+            ovm = O.v_map(ova, ov[:, :, t])
+            assert (N(v_maps[k - 1]) != ovm).mean() < 1e-4
+            ovmg = O.v_map(ovg, ov[:, :, t]) * flows_use.reshape(-1, 1, 1, 1, 1)
+            assert (N(v_maps_gt[k - 1]) != ovmg).mean() < 1e-4
+    # gradients reach the predicted flows through the warps (what the reference's training exercises)
+    loss = sum((xa * xa).sum() for xa in xs_al)
+    grads = torch.autograd.grad(loss, tflows)
+    for k in range(3):
+        ox, ov = sets[k][0].numpy(), sets[k][1].numpy()
+        oxa, _ = O.align_set(ox[:, :, r_list], ov[:, :, r_list], flows[k])
+        _, ogf = O.align_set_bwd(ox[:, :, r_list], ov[:, :, r_list], flows[k], 2 * oxa)
+        assert_close(N(grads[k]), ogf, rtol=1e-3, atol=1e-4, what="g_flow scale %d" % k)
+    # inference unit
+    xa, va, vm = runners.infer_step_propagate(_standin_model(tflows), T(x[:, :, t]), T(m[:, :, t]), T(x[:, :, r_list]), T(m[:, :, r_list]))
+    oxa, ova = O.align_set(x[:, :, r_list], 1 - m[:, :, r_list], flows[2])
+    assert_close(N(xa), oxa, what="infer x_aligned")
+    assert_exact(N(va), ova, what="infer v_aligned")
+    assert_exact(N(vm), O.v_map(ova, 1 - m[:, :, t]), what="infer v_map")
