@@ -3,7 +3,7 @@
 and the other correlation variants.  Not the headline bench (that is bench.py); prints one JSON line per op with the
 achieved algorithmic GB/s (or TFLOP/s) against the MI355X peak, timed with HIP events on the launch stream.
 
-    python bench_ops.py [--iters 20] [--ops warp,affine,ctx,corr_model,argmax]
+    python bench_ops.py [--iters 20] [--ops warp,affine,ctx,corr_model,argmax,cpu]      (cpu = the numpy port on the host cores)
 """
 import argparse
 import json
@@ -140,13 +140,44 @@ def bench_argmax(iters):
     report("corr4d + corr_to_flow fused 64x64 C=256 x16 pairs", ms, flops=2.0 * 4096 * 4096 * C * B * F, units=B * F)
 
 
+def bench_cpu(iters):
+    """The CPU restatement of the reference (numpy oracle, `kind: port`) on the host cores, on bounded samples of the same
+    workloads: pairs/s beside the GPU rows above (a reported baseline, not a target)."""
+    import time
+    import numpy as np
+    from oracle import tcl_oracle as O
+    rng = np.random.default_rng(0)
+    def run(name, fn, units, budget=6.0):
+        fn()
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget:
+            fn(); n += 1
+        el = time.perf_counter() - t0
+        print(json.dumps({"op": name, "cpu_baseline": {"value": round(units * n / el, 2), "unit": "pairs/s", "kind": "port",
+                                                       "cores": os.cpu_count() if "BLAS" in name else 1,
+                                                       "sample": "%d calls of %d pairs in %.1f s" % (n, units, el)}}), flush=True)
+    B, R, H, W = 1, 4, 256, 256
+    x = rng.random((B, 3, R, H, W)).astype(np.float32)
+    v = (rng.random((B, 1, R, H, W)) < 0.85).astype(np.float32)
+    ident = np.stack(np.meshgrid(np.linspace(-1, 1, W), np.linspace(-1, 1, H)), axis=-1).astype(np.float32)
+    flow = (ident[None, None] * 1.05 + 0.1).astype(np.float32).repeat(R, axis=1)
+    run("CPU port: align_set fwd 256^2 (C3)", lambda: O.align_set(x, v, flow), B * R)
+    cot = rng.standard_normal(x.shape).astype(np.float32)
+    run("CPU port: align_set bwd 256^2 (C3)", lambda: O.align_set_bwd(x, v, flow, cot), B * R)
+    C, R, h, w, H, W = 128, 10, 30, 53, 240, 424
+    cf = (0.05 * rng.standard_normal((1, C, R + 1, h, w))).astype(np.float32)
+    v_t = (rng.random((1, 1, H, W)) < 0.6).astype(np.float32)
+    v_al = (rng.random((1, 1, R, H, W)) < 0.7).astype(np.float32)
+    run("CPU port: context matching fwd (C4)", lambda: O.context_matching(cf, v_t, v_al, False, "default"), R)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ops", default="warp,affine,ctx,corr_model,argmax")
     a = ap.parse_args()
     torch.cuda.set_device(0)
-    table = dict(warp=bench_warp, affine=bench_affine, ctx=bench_ctx, corr_model=bench_corr_model, argmax=bench_argmax)
+    table = dict(warp=bench_warp, affine=bench_affine, ctx=bench_ctx, corr_model=bench_corr_model, argmax=bench_argmax, cpu=bench_cpu)
     for op in a.ops.split(","):
         table[op](a.iters)
 
