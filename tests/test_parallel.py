@@ -83,3 +83,17 @@ def test_two_ranks_gloo():
         ret = mgr.dict()
         mp.spawn(_worker, args=(world_size, _free_port(), ret), nprocs=world_size, join=True)
         assert dict(ret) == {0: (True, True), 1: (True, True)}
+
+
+def test_c5_network_matches_the_reference_parameter_count():
+    """ThesisInpaintingVisible = RRDBNet(in=9, out=3, nb=20): 14,690,883 parameters, i.e. the 58.76 MB gradient
+    the data-parallel step all-reduces; three 25 MiB buckets."""
+    from master_thesis_amd import harness_c5
+    net = harness_c5.InpaintingNet(nb=20)
+    n = sum(p.numel() for p in net.parameters())
+    assert n == 14690883
+    buckets = parallel.GradientBuckets(net.parameters())
+    assert buckets.nbytes() == 58763532 and len(buckets.buckets) == 3
+    small = harness_c5.InpaintingNet(nb=1)
+    y_hat, y_comp = small(torch.rand(1, 3, 16, 16), torch.ones(1, 1, 16, 16), torch.rand(1, 3, 2, 16, 16), torch.ones(1, 1, 2, 16, 16), torch.zeros(1, 1, 2, 16, 16))
+    assert y_hat.shape == (1, 3, 2, 16, 16) and y_comp.shape == (1, 3, 2, 16, 16)
