@@ -3,7 +3,7 @@
 and the other correlation variants.  Not the headline bench (that is bench.py); prints one JSON line per op with the
 achieved algorithmic GB/s (or TFLOP/s) against the MI355X peak, timed with HIP events on the launch stream.
 
-    python bench_ops.py [--iters 20] [--ops warp,affine,ctx,corr_model,argmax,cpu]      (cpu = the numpy port on the host cores)
+    python bench_ops.py [--iters 20] [--ops warp,affine,ctx,corr_model,argmax,movement,sched,cpu]      (cpu = the numpy port on the host cores)
 """
 import argparse
 import json
@@ -140,6 +140,74 @@ def bench_argmax(iters):
     report("corr4d + corr_to_flow fused 64x64 C=256 x16 pairs", ms, flops=2.0 * 4096 * 4096 * C * B * F, units=B * F)
 
 
+def bench_movement(iters):
+    """N4: MovementSimulator.simulate_movement_batch, 64 frames -> 64 x 5-frame sequences at 256^2, beside the stock
+    torch formulation the reference uses (repeat + affine_grid + grid_sample)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from master_thesis_amd.utils.movement import MovementSimulator
+    B, n, H, W = 64, 5, 256, 256
+    sim = MovementSimulator(20, 0.1, 0.2)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(6)).to(DEV)
+    np.random.seed(0)
+    _, _, mats = sim.simulate_movement_batch(x, n)
+    ms = timed(lambda: sim.simulate_movement_batch(x, n, mats), iters)
+    npix = B * n * H * W
+    report("simulate_movement_batch 64x5 256^2 (N4), incl. host 3x3 chain", ms, bytes_=B * 3 * H * W * 4 + npix * (3 * 4 + 8), units=B * n, unit_name="frames",
+           note="read x once per sequence, write y(3) + flow_inv(2); the rest of the wall time is the host 3x3 chain + 2 H2D copies")
+    from master_thesis_amd import _lib, _ops
+    theta = torch.eye(2, 3).repeat(B * n, 1, 1).to(DEV) + 0.05 * torch.randn(B * n, 2, 3, generator=torch.Generator().manual_seed(7)).to(DEV)
+    xe = x.unsqueeze(2).expand(B, 3, n, H, W)
+    ms = timed(lambda: (_ops.WarpFn.apply(xe, None, None, theta, True, _lib.VMODE_NONE), _ops.AffineGridFn.apply(theta, H, W, True)), iters)
+    report("  device part only: warp(theta, frame stride 0) + affine_grid", ms, bytes_=B * 3 * H * W * 4 + npix * (3 * 4 + 8), units=B * n, unit_name="frames")
+    def stock():
+        flow = F.affine_grid(theta, [B * n, 3, H, W], align_corners=True)
+        F.affine_grid(theta, [B * n, 3, H, W], align_corners=True)
+        return F.grid_sample(x.unsqueeze(1).repeat(1, n, 1, 1, 1).reshape(B * n, 3, H, W), flow, align_corners=True)
+    ms = timed(stock, iters)
+    report("  stock ATen formulation of the same (repeat + 2x affine_grid + grid_sample)", ms, bytes_=B * 3 * H * W * 4 + npix * (3 * 4 + 8), units=B * n, unit_name="frames")
+
+
+def bench_sched(iters):
+    """N3: the copy-and-propagate scheduler on 32 sequences of 8 frames at 256^2, batched in lock-step vs the reference's
+    one-sequence-at-a-time order (same HIP ops, same weight-free stand-in networks from tests/standins.py)."""
+    import time
+    import numpy as np
+    from master_thesis_amd import schedulers as S
+    from tests import standins
+    n_seq, f, H, W = 32, 8, 256, 256
+    seqs = [standins.moving_hole_sequence(i, 3, f, H, W, 40 + 4 * (i % 8), 6 + i % 5) for i in range(n_seq)]
+    x = torch.from_numpy(np.stack([s[0] for s in seqs])).to(DEV)
+    m = torch.from_numpy(np.stack([s[1] for s in seqs])).to(DEV)
+    pairs = [0]
+    step = S.runners.ThesisInpaintingRunner.infer_step_propagate
+    def counted(*a):
+        pairs[0] += a[2].size(0)
+        return step(*a)
+    def run(batched):
+        S.runners.ThesisInpaintingRunner.infer_step_propagate = staticmethod(counted)
+        try:
+            pairs[0] = 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if batched:
+                y = S.inpainting_algorithm_cp_batched(x, m, standins.torch_flow, standins.torch_inpaint, N=4, s=1, e=1)
+            else:
+                y = torch.stack([S.inpainting_algorithm_cp(x[i], m[i], standins.torch_flow, standins.torch_inpaint, N=4, s=1, e=1) for i in range(n_seq)])
+            torch.cuda.synchronize()
+            return y, time.perf_counter() - t0, pairs[0]
+        finally:
+            S.runners.ThesisInpaintingRunner.infer_step_propagate = staticmethod(step)
+    run(True)
+    yb, tb, pb = run(True)
+    ys, ts, ps = run(False)
+    assert pb == ps and torch.allclose(yb, ys, atol=1e-6)
+    print(json.dumps({"op": "inpainting_algorithm_cp, 32 sequences x 8 frames 256^2, N=4 (N3)", "pairs": pb,
+                      "batched_ms": round(tb * 1e3, 2), "batched_pairs_per_s": round(pb / tb, 1),
+                      "sequential_ms": round(ts * 1e3, 2), "sequential_pairs_per_s": round(ps / ts, 1),
+                      "speedup": round(ts / tb, 2), "note": "identical outputs; stand-in networks, so the time is the schedulers' own ops + launches"}), flush=True)
+
+
 def bench_cpu(iters):
     """The CPU restatement of the reference (numpy oracle, `kind: port`) on the host cores, on bounded samples of the same
     workloads: pairs/s beside the GPU rows above (a reported baseline, not a target)."""
@@ -177,7 +245,7 @@ def main():
     ap.add_argument("--ops", default="warp,affine,ctx,corr_model,argmax")
     a = ap.parse_args()
     torch.cuda.set_device(0)
-    table = dict(warp=bench_warp, affine=bench_affine, ctx=bench_ctx, corr_model=bench_corr_model, argmax=bench_argmax, cpu=bench_cpu)
+    table = dict(movement=bench_movement, sched=bench_sched, warp=bench_warp, affine=bench_affine, ctx=bench_ctx, corr_model=bench_corr_model, argmax=bench_argmax, cpu=bench_cpu)
     for op in a.ops.split(","):
         table[op](a.iters)
 

@@ -142,6 +142,11 @@ int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_sf, int64_t 
                  int64_t NB, int64_t NF, int64_t C, int64_t H, int64_t W, int align_corners,
                  void *workspace, size_t workspace_bytes, void *stream);
 
+/*   F.affine_grid(theta, [N,C,H,W], align_corners) materialised: theta (N,2,3) -> grid (N,H,W,2).  The grid of
+ *   MovementSimulator.simulate_movement (utils/movement.py:54-55, align_corners=1) and of CPNet.align
+ *   (models/cpn.py:286, align_corners=0); tcl_warp_fwd(theta=...) samples through the same positions without storing them. */
+int tcl_affine_grid(const float *theta, float *grid, int64_t N, int64_t H, int64_t W, int align_corners, void *stream);
+
 /* T1  v_map = clamp(v_ref_aligned - v_target, 0, 1); thesis_dfpn/runner.py:137-138,158; models/cpn_original.py:287.
  *   v_aligned (B,F,P) dense, v_target (B,P) -> out (B,F,P). */
 int tcl_vmap(const float *v_aligned, const float *v_target, float *out, int64_t B, int64_t F, int64_t P, void *stream);

@@ -34,6 +34,7 @@ SIGNATURES = {
     "tcl_warp_bwd_workspace_bytes": (_SZ, [_I64] * 4 + [_INT]),
     "tcl_warp_bwd": (_INT, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _P, _P]
                      + [_I64] * 5 + [_INT, _P, _SZ, _P]),
+    "tcl_affine_grid": (_INT, [_P] * 2 + [_I64] * 3 + [_INT, _P]),
     "tcl_vmap": (_INT, [_P] * 3 + [_I64] * 3 + [_P]),
     "tcl_masked_softmax_fwd": (_INT, [_P] * 3 + [_I64] * 4 + [_P]),
     "tcl_masked_softmax_bwd": (_INT, [_P] * 4 + [_I64] * 4 + [_P]),

@@ -194,6 +194,31 @@ class WarpFn(torch.autograd.Function):
         return g_x, None, g_grid, g_theta, None, None
 
 
+class AffineGridFn(torch.autograd.Function):
+    """theta (N,2,3) -> grid (N,H,W,2) = F.affine_grid(theta, (N,*,H,W), align_corners)."""
+
+    @staticmethod
+    def forward(ctx, theta, h, w, align_corners):
+        dev = _require_device(theta)
+        n = theta.shape[0]
+        if tuple(theta.shape[1:]) != (2, 3):
+            raise ValueError("affine_grid expects theta (N,2,3), got %s" % (tuple(theta.shape),))
+        tc = theta.contiguous()
+        grid = torch.empty((n, h, w, 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("tcl_affine_grid", _p(tc), _p(grid), n, h, w, int(bool(align_corners)), _stream(dev))
+        ctx.meta = (h, w, bool(align_corners))
+        return grid
+
+    @staticmethod
+    def backward(ctx, g):
+        # grid = base @ theta^T with a constant base grid: a (6 x HW) reduction per image; data-side op, torch suffices
+        h, w, ac = ctx.meta
+        base = torch.nn.functional.affine_grid(torch.eye(2, 3, device=g.device).unsqueeze(0), (1, 1, h, w), align_corners=ac)
+        base = torch.cat([base, torch.ones_like(base[..., :1])], -1).reshape(1, h * w, 3)
+        return torch.matmul(g.reshape(g.shape[0], h * w, 2).transpose(1, 2), base), None, None, None
+
+
 def vmap(v_aligned, v_target):
     """clamp(v_aligned - v_target.unsqueeze(2), 0, 1): (B,1,F,H,W), (B,1,H,W) -> (B,1,F,H,W)."""
     dev = _require_device(v_aligned, v_target)

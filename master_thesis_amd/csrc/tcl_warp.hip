@@ -302,6 +302,19 @@ __global__ void vmap_kernel(const float *va, const float *vt, float *out, int64_
   }
 }
 
+// F.affine_grid(theta, (N,*,H,W), align_corners): the same positions sample_pos<true> derives on the fly, materialised
+// (utils/movement.py:54-55 returns the inverse movement as a grid).  One float2 per lane, 2-D grid like the warp.
+__global__ void __launch_bounds__(256) affine_grid_kernel(const float *__restrict__ theta, float2 *__restrict__ out, int H, int W,
+                                                          float stepx, float stepy, int ac) {
+  const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const int y = p / W, x = p - y * W;
+  const float *th = theta + (int64_t)n * 6;
+  const float xs = base_coord_step(x, W, stepx, ac), ys = base_coord_step(y, H, stepy, ac);
+  out[(int64_t)n * H * W + p] = make_float2(__fadd_rn(__fadd_rn(__fmul_rn(th[0], xs), __fmul_rn(th[1], ys)), th[2]),
+                                            __fadd_rn(__fadd_rn(__fmul_rn(th[3], xs), __fmul_rn(th[4], ys)), th[5]));
+}
+
 static inline float lin_step(int64_t n) { return n > 1 ? 2.f / (float)(n - 1) : 0.f; }
 
 }  // namespace tcl
@@ -347,6 +360,15 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
 #undef TCL_LAUNCH_WARP_V
 #undef TCL_LAUNCH_WARP
   return check_launch("tcl_warp_fwd");
+}
+
+extern "C" int tcl_affine_grid(const float *theta, float *grid, int64_t N, int64_t H, int64_t W, int align_corners, void *stream) {
+  TCL_REQUIRE(N > 0 && H > 0 && W > 0 && H * W < (1LL << 30) && N < 65536, TCL_ERR_SHAPE, "tcl_affine_grid: bad shape N=%ld H=%ld W=%ld", (long)N,
+              (long)H, (long)W);
+  TCL_REQUIRE(theta && grid && aligned(grid, 8), TCL_ERR_ARG, "tcl_affine_grid: NULL / misaligned pointer");
+  hipLaunchKernelGGL(affine_grid_kernel, dim3((unsigned)cdiv(H * W, 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream, theta, (float2 *)grid,
+                     (int)H, (int)W, lin_step(W), lin_step(H), align_corners);
+  return check_launch("tcl_affine_grid");
 }
 
 extern "C" size_t tcl_warp_bwd_workspace_bytes(int64_t NB, int64_t NF, int64_t H, int64_t W, int have_theta) {

@@ -1,4 +1,4 @@
-"""The static step functions of the reference's alignment runner on top of the HIP ops.
+"""The static step functions of the reference's runners on top of the HIP ops.
 
 Mirrors `ThesisAlignmentRunner.train_step_propagate` (thesis_dfpn/runner.py:104-151) and `infer_step_propagate`
 (thesis_dfpn/runner.py:153-159): same arguments, same returned tuple.  `model` is any callable with the alignment
@@ -68,3 +68,61 @@ def infer_step_propagate(model, x_target, m_target, x_ref, m_ref):
     x_ref_aligned, v_ref_aligned = flow_ops.align_set(x_ref, 1 - m_ref, flow_256)
     v_map = _ops.vmap(v_ref_aligned, 1 - m_target)
     return x_ref_aligned, v_ref_aligned, v_map
+
+
+class ThesisAlignmentRunner:
+    """Namespace with the reference class's static step functions (thesis_dfpn/runner.py:104-159)."""
+    train_step_propagate = staticmethod(train_step_propagate)
+    infer_step_propagate = staticmethod(infer_step_propagate)
+
+
+class ThesisCPNRunner:
+    @staticmethod
+    def infer_alignment_step_propagate(model, x_target, m_target, x_refs, m_refs):
+        """thesis_cpn/runner.py:96-98: the CPN aligner's own `align` (affine warp; models/cpn_original.py:260-290)."""
+        return model.align(x_target, m_target, x_refs, m_refs)
+
+
+def _align_step(model_alignment, x_target, m_target, x_ref, m_ref):
+    # the reference dispatches on isinstance(ThesisAlignmentModel) (thesis_inpainting/runner.py:88-95); the dense-flow
+    # aligner is a plain callable here, the CPN aligner is recognised by its `align` method
+    if hasattr(model_alignment, 'align'):
+        return ThesisCPNRunner.infer_alignment_step_propagate(model_alignment, x_target, m_target, x_ref, m_ref)
+    return infer_step_propagate(model_alignment, x_target, m_target, x_ref, m_ref)
+
+
+class ThesisInpaintingRunner:
+    """Static step functions of thesis_inpainting/runner.py:85-128.  `model_alignment` is frozen (no_grad); `model` is the
+    inpainting network `model(x_target, v_target, x_ref_aligned, v_ref_aligned, v_map) -> (y_hat, y_hat_comp)`
+    (models/thesis_inpainting.py:14-36)."""
+
+    @staticmethod
+    def train_step_propagate(model_alignment, model, x_target, m_target, x_ref, m_ref):
+        with torch.no_grad():
+            x_ref_aligned, v_ref_aligned, v_map = _align_step(model_alignment, x_target, m_target, x_ref, m_ref)
+        y_hat, y_hat_comp = model(x_target, 1 - m_target, x_ref_aligned, v_ref_aligned, v_map)
+        return x_ref_aligned, v_ref_aligned, v_map, y_hat, y_hat_comp
+
+    @staticmethod
+    def infer_step_propagate(model_alignment, model, x_target, m_target, x_ref, m_ref):
+        with torch.no_grad():
+            return ThesisInpaintingRunner.train_step_propagate(model_alignment, model, x_target, m_target, x_ref, m_ref)
+
+    @staticmethod
+    def compute_loss(utils_losses, y_target, v_target, y_hat, y_hat_comp, v_map):
+        """Non-hole / visible-hole / non-visible-hole L1 + perceptual + gradient terms, weights 0.5 / 2 / 1 / 0.5 / 1.
+        `utils_losses` provides masked_l1, perceptual and grad (utils/losses.py); thesis_inpainting/runner.py:113-128."""
+        b, c, h, w = y_target.size()
+        f = y_hat.size(2)
+        target_img = y_target.unsqueeze(2).repeat(1, 1, f, 1, 1)
+        nh_mask = v_target.unsqueeze(2).repeat(1, 1, f, 1, 1)
+        vh_mask = v_map
+        nvh_mask = (1 - nh_mask) - vh_mask
+        loss_nh = utils_losses.masked_l1(y_hat, target_img, nh_mask, reduction='sum', weight=0.50)
+        loss_vh = utils_losses.masked_l1(y_hat, target_img, vh_mask, reduction='sum', weight=2)
+        loss_nvh = utils_losses.masked_l1(y_hat_comp, target_img, nvh_mask, reduction='sum', weight=1)
+        loss_perceptual, *_ = utils_losses.perceptual(
+            y_hat.transpose(1, 2).reshape(-1, c, h, w), target_img.transpose(1, 2).reshape(-1, c, h, w), weight=0.50)
+        loss_grad = utils_losses.grad(y_hat.squeeze(2), target_img.squeeze(2), reduction='mean', weight=1)
+        loss = loss_nh + loss_vh + loss_nvh + loss_perceptual + loss_grad
+        return loss, [loss_nh, loss_vh, loss_nvh, loss_perceptual, loss_grad]

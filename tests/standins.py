@@ -1,0 +1,99 @@
+"""Deterministic stand-ins for the networks around the hot path, in a torch and a numpy flavour.
+
+The sequence schedulers and runner step functions take the alignment network and the inpainting network as arguments.
+To pin OUR schedulers against the reference's (tests/golden/make_golden_sequences.py runs the real reference loops) both
+sides need the same "networks": closed-form functions with no weights.  The torch flavour is device-agnostic (CPU inside
+the golden generator, GPU in the parity tests); the numpy flavour feeds the oracle.
+
+  aligner      : flow_256 = identity grid + a constant shift of (+1.3, -0.7) pixels  (far from the .5 rounding ties
+                 of the nearest-neighbour visibility warp, so masks stay bit-exact across float implementations)
+  cpn aligner  : `.align` with a constant theta (small rotation + shift), through the affine warp
+  inpainter    : y_hat = clamp(0.2 + 0.5 * x_ref_aligned * v_ref_aligned + 0.3 * x_target, 0, 1);  y_hat_comp as
+                 models/thesis_inpainting.py:33
+  cpn model    : (y_hat, y_hat_comp) with y_hat = mean over refs of x_refs * (1 - m_refs)
+"""
+import numpy as np
+
+SHIFT_PX = (1.3, -0.7)
+THETA = ((0.98, 0.05, 0.06), (-0.04, 1.01, -0.03))
+
+
+# ------------------------------------------------------------------------------------------------ torch flavour
+def torch_identity_grid(h, w, device):
+    import torch
+    ys = torch.linspace(-1, 1, h, device=device).view(h, 1).expand(h, w)
+    xs = torch.linspace(-1, 1, w, device=device).view(1, w).expand(h, w)
+    return torch.stack([xs, ys], dim=2)
+
+
+def torch_flow(x_target, m_target, x_ref, m_ref):
+    """Call signature of ThesisAlignmentModel.forward (models/thesis_alignment.py:177-207) -> (corr, f16, f64, f256)."""
+    import torch
+    b, c, f, h, w = x_ref.size()
+    shift = torch.tensor([SHIFT_PX[0] * 2 / (w - 1), SHIFT_PX[1] * 2 / (h - 1)], device=x_ref.device)
+    flow = (torch_identity_grid(h, w, x_ref.device) + shift).view(1, 1, h, w, 2).repeat(b, f, 1, 1, 1)
+    return None, None, None, flow
+
+
+def torch_inpaint(x_target, v_target, x_refs_aligned, v_refs_aligned, v_maps):
+    """Call signature of ThesisInpaintingVisible.forward (models/thesis_inpainting.py:14-36)."""
+    import torch
+    f = x_refs_aligned.size(2)
+    x_t = x_target.unsqueeze(2).repeat(1, 1, f, 1, 1)
+    v_t = v_target.unsqueeze(2).repeat(1, 1, f, 1, 1)
+    y_hat = torch.clamp(0.2 + 0.5 * x_refs_aligned * v_refs_aligned + 0.3 * x_t, 0, 1)
+    return y_hat, v_t * x_t + (1 - v_t) * y_hat
+
+
+def torch_cpn_model(x_target, m_target, x_refs, m_refs):
+    """Call signature of CPNOriginal.forward (models/cpn_original.py:255-258)."""
+    y_hat = (x_refs * (1 - m_refs)).mean(2)
+    return y_hat, (1 - m_target) * x_target + m_target * y_hat
+
+
+def torch_theta(n, device):
+    import torch
+    return torch.tensor(THETA, device=device).view(1, 2, 3).repeat(n, 1, 1)
+
+
+# ------------------------------------------------------------------------------------------------ numpy flavour
+def np_flow(x_ref):
+    b, c, f, h, w = x_ref.shape
+    xs = np.linspace(-1, 1, w, dtype=np.float64).astype(np.float32)
+    ys = np.linspace(-1, 1, h, dtype=np.float64).astype(np.float32)
+    grid = np.stack([np.broadcast_to(xs[None, :], (h, w)), np.broadcast_to(ys[:, None], (h, w))], axis=2).astype(np.float32)
+    shift = np.array([np.float32(SHIFT_PX[0] * 2 / (w - 1)), np.float32(SHIFT_PX[1] * 2 / (h - 1))], dtype=np.float32)
+    return np.broadcast_to((grid + shift)[None, None], (b, f, h, w, 2)).astype(np.float32).copy()
+
+
+def np_inpaint(x_target, v_target, x_refs_aligned, v_refs_aligned, v_maps):
+    f = x_refs_aligned.shape[2]
+    x_t = np.repeat(x_target[:, :, None], f, axis=2)
+    v_t = np.repeat(v_target[:, :, None], f, axis=2)
+    y_hat = np.clip(np.float32(0.2) + np.float32(0.5) * x_refs_aligned * v_refs_aligned + np.float32(0.3) * x_t, 0, 1).astype(np.float32)
+    return y_hat, (v_t * x_t + (1 - v_t) * y_hat).astype(np.float32)
+
+
+def np_cpn_model(x_target, m_target, x_refs, m_refs):
+    y_hat = (x_refs * (1 - m_refs)).mean(2, dtype=np.float32)
+    return y_hat, ((1 - m_target) * x_target + m_target * y_hat).astype(np.float32)
+
+
+def np_theta(n):
+    return np.broadcast_to(np.array(THETA, dtype=np.float32)[None], (n, 2, 3)).copy()
+
+
+# ------------------------------------------------------------------------------------------------ inputs
+def moving_hole_sequence(seed, c, f, h, w, hole, step):
+    """x (c,f,h,w) U[0,1) and m (1,f,h,w): a `hole` x `hole` square drifting by `step` px per frame (plus a second,
+    static one on odd seeds so that some pixels are visible in no neighbour)."""
+    rng = np.random.RandomState(seed)
+    x = rng.rand(c, f, h, w).astype(np.float32)
+    m = np.zeros((1, f, h, w), np.float32)
+    y0, x0 = rng.randint(1, h - hole - 1), rng.randint(1, max(2, w // 3))
+    for t in range(f):
+        xx = min(max(x0 + step * t, 0), w - hole)
+        m[0, t, y0:y0 + hole, xx:xx + hole] = 1
+    if seed % 2 == 1:
+        m[0, :, h - 4:h - 1, w - 4:w - 1] = 1
+    return x, m
