@@ -52,38 +52,71 @@ __global__ void __launch_bounds__(256) dilate_cross3_kernel(const float *__restr
   }
 }
 
+// PX consecutive floats per lane as one 4 / 8 / 16-byte access (the pointer is PX*4-byte aligned by construction)
+template <int PX> __device__ __forceinline__ void ldpx(const float *p, float (&v)[PX]) {
+  if (PX == 4) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[PX > 1 ? 1 : 0] = t.y; v[PX > 2 ? 2 : 0] = t.z; v[PX - 1] = t.w; }
+  else if (PX == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[PX - 1] = t.y; }
+  else v[0] = p[0];
+}
+template <int PX> __device__ __forceinline__ void stpx(float *p, const float (&v)[PX]) {
+  if (PX == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[PX > 1 ? 1 : 0], v[PX > 2 ? 2 : 0], v[PX - 1]);
+  else if (PX == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[PX - 1]);
+  else p[0] = v[0];
+}
+template <int PX> __device__ __forceinline__ void stpx_stream(float *p, const float (&v)[PX]) {
+  if (PX == 4) st_stream4(p, v[0], v[PX > 1 ? 1 : 0], v[PX > 2 ? 2 : 0], v[PX - 1]);
+  else if (PX == 2) st_stream2(p, v[0], v[PX - 1]);
+  else st_stream(p, v[0]);
+}
+
 // ref_importance (B,3,R+1,H,W): planes = upsampled c_match with a middle plane inserted at R/2, hole border painted red.
-// 2-D grid (chunk of 256 pixels, b * (R+1) + j); straight-line: every load is unconditional (clamped neighbours /
-// clamped plane index), selected afterwards.
+// 2-D grid (chunk of 256*PX pixels, b * (R+1) + j); PX consecutive pixels of one row per lane (PX = 4 when W % 4 == 0:
+// 16-byte loads and stores, 4x fewer workgroups: the one-pixel version was bound by workgroup dispatch, not by HBM).
+// Straight-line: every load is unconditional (clamped neighbours / clamped plane index), selected afterwards.
+template <int PX>
 __global__ void __launch_bounds__(256) ref_importance_kernel(const float *__restrict__ c_match, const float *__restrict__ v_t,
                                                              float *__restrict__ out, int B, int R, int h, int w, int H, int W,
                                                              int middle_is_vt, float sh, float sw) {
   const int HW = H * W;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int pix = (blockIdx.x * 256 + threadIdx.x) * PX;
   if (pix >= HW) return;
   const int bj = blockIdx.y, b = bj / (R + 1), j = bj - b * (R + 1);
-  const int y = pix / W, x = pix - y * W;
+  const int y = pix / W, x = pix - y * W;   // PX | W: the PX pixels share the row
   const float *vt = v_t + (int64_t)b * HW;
   const bool middle = j == R / 2;
   const int r = min(j < R / 2 ? j : j - 1, R - 1);
   const float *p = c_match + ((int64_t)b * R + r) * h * w;
-  const LinTap ty = linear_tap(y, h, sh), tx = linear_tap(x, w, sw);
+  const LinTap ty = linear_tap(y, h, sh);
   // loads
-  const float vc = vt[pix];
-  const float vn = vt[y > 0 ? pix - W : pix], vs = vt[y < H - 1 ? pix + W : pix];
-  const float vw = vt[x > 0 ? pix - 1 : pix], ve = vt[x < W - 1 ? pix + 1 : pix];
-  const float p00 = p[ty.i0 * w + tx.i0], p01 = p[ty.i0 * w + tx.i1], p10 = p[ty.i1 * w + tx.i0], p11 = p[ty.i1 * w + tx.i1];
-  // border = dilate(hole) - hole > 0 with hole = 1 - v_t; dilation of (1 - v) over the 3x3 cross
-  const float hole = 1.f - vc;
-  const float dil = fmaxf(fmaxf(fmaxf(hole, 1.f - vn), fmaxf(1.f - vs, 1.f - vw)), 1.f - ve);
-  const float border = (dil - hole) > 0.f ? 1.f : 0.f;
-  const float up = bilerp(p00, p01, p10, p11, tx, ty);
-  const float val = middle ? (middle_is_vt ? vc : 0.f) : up;
-  const float keep = val * (1.f - border);
+  float vc[PX], vn[PX], vs[PX], p00[PX], p01[PX], p10[PX], p11[PX];
+  LinTap tx[PX];
+  ldpx<PX>(vt + pix, vc);
+  ldpx<PX>(vt + (y > 0 ? pix - W : pix), vn);
+  ldpx<PX>(vt + (y < H - 1 ? pix + W : pix), vs);
+  const float vw = vt[x > 0 ? pix - 1 : pix], ve = vt[x + PX < W ? pix + PX : pix + PX - 1];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) {
+    tx[e] = linear_tap(x + e, w, sw);
+    p00[e] = p[ty.i0 * w + tx[e].i0]; p01[e] = p[ty.i0 * w + tx[e].i1];
+    p10[e] = p[ty.i1 * w + tx[e].i0]; p11[e] = p[ty.i1 * w + tx[e].i1];
+  }
+  float red[PX], keep[PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) {
+    // border = dilate(hole) - hole > 0 with hole = 1 - v_t; dilation of (1 - v) over the 3x3 cross
+    const float west = e == 0 ? vw : vc[e > 0 ? e - 1 : 0], east = e == PX - 1 ? ve : vc[e < PX - 1 ? e + 1 : 0];
+    const float hole = 1.f - vc[e];
+    const float dil = fmaxf(fmaxf(fmaxf(hole, 1.f - vn[e]), fmaxf(1.f - vs[e], 1.f - west)), 1.f - east);
+    const float border = (dil - hole) > 0.f ? 1.f : 0.f;
+    const float up = bilerp(p00[e], p01[e], p10[e], p11[e], tx[e], ty);
+    const float val = middle ? (middle_is_vt ? vc[e] : 0.f) : up;
+    keep[e] = val * (1.f - border);
+    red[e] = keep[e] + border;
+  }
   float *o = out + ((int64_t)b * 3 * (R + 1) + j) * HW + pix;
-  o[0] = keep + border;
-  o[(int64_t)(R + 1) * HW] = keep;
-  o[(int64_t)2 * (R + 1) * HW] = keep;
+  stpx_stream<PX>(o, red);   // 430 MB of write-only output at C4
+  stpx_stream<PX>(o + (int64_t)(R + 1) * HW, keep);
+  stpx_stream<PX>(o + (int64_t)2 * (R + 1) * HW, keep);
 }
 
 // ------------------------------------------------------------------------------------------ A5 generic masked softmax
@@ -178,15 +211,6 @@ static CtxWs ctx_ws(void *base, int64_t B, int64_t C, int64_t R, int64_t hw) {
   w.mbits = (unsigned *)take((size_t)w.passes * B * hw);
   w.bytes = off;
   return w;
-}
-
-template <int PX> __device__ __forceinline__ void ldpx(const float *p, float (&v)[PX]) {
-  if (PX == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[PX - 1] = t.y; }
-  else v[0] = p[0];
-}
-template <int PX> __device__ __forceinline__ void stpx(float *p, const float (&v)[PX]) {
-  if (PX == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[PX - 1]);
-  else p[0] = v[0];
 }
 
 // both mask resizes of the forward pass in one launch: image n of B*(R+1) is v_t[b] (j == 0) or v_aligned[b][j-1]
@@ -384,11 +408,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 #pragma unroll
         for (int e = 0; e < PX; ++e) acc[e] = ft[e] * vtx[e] + acc[e];
       }
-      stpx<PX>(oacc + x, acc);
-    } else {
-      if (r0 == 0) stpx<PX>(o + (int64_t)c * hw + x, ft);
-      stpx<PX>(oacc + x, acc);
+    } else if (r0 == 0) {
+      stpx_stream<PX>(o + (int64_t)c * hw + x, ft);
     }
+    if (last) stpx_stream<PX>(oacc + x, acc);   // the running sum is only read back by a later pass (R > CTX_RMAX)
+    else stpx<PX>(oacc + x, acc);
   }
 }
 
@@ -559,7 +583,7 @@ __global__ void __launch_bounds__(256) ctx_bwd_feats_kernel(const float *__restr
       g_ft[e] += k * fr[e];
       o[e] = g_out[e] * cm[e] + k * ft[e];
     }
-    stpx<PX>(g_cf + base + (int64_t)(r + 1) * hw, o);
+    stpx<PX>(g_cf + base + (int64_t)(r + 1) * hw, o);   // plain stores: streaming ones measured 2 % slower here
   }
   stpx<PX>(g_cf + base, g_ft);
 }
@@ -596,8 +620,12 @@ extern "C" int tcl_ref_importance(const float *c_match, const float *v_t, float 
   TCL_REQUIRE(c_match && v_t && ref_importance, TCL_ERR_ARG, "tcl_ref_importance: NULL pointer");
   TCL_REQUIRE(B * (R + 1) < 65536, TCL_ERR_SHAPE, "tcl_ref_importance: too many planes for one launch (%ld)", (long)(B * (R + 1)));
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;   // IEEE division, as __fdiv_rn
-  hipLaunchKernelGGL(ref_importance_kernel, dim3((unsigned)cdiv(H * W, 256), (unsigned)(B * (R + 1))), dim3(256), 0, (hipStream_t)stream,
-                     c_match, v_t, ref_importance, (int)B, (int)R, (int)h, (int)w, (int)H, (int)W, middle_is_vt, sh, sw);
+  if (W % 4 == 0 && aligned(v_t, 16) && aligned(ref_importance, 16))
+    hipLaunchKernelGGL(ref_importance_kernel<4>, dim3((unsigned)cdiv(H * W, 1024), (unsigned)(B * (R + 1))), dim3(256), 0, (hipStream_t)stream,
+                       c_match, v_t, ref_importance, (int)B, (int)R, (int)h, (int)w, (int)H, (int)W, middle_is_vt, sh, sw);
+  else
+    hipLaunchKernelGGL(ref_importance_kernel<1>, dim3((unsigned)cdiv(H * W, 256), (unsigned)(B * (R + 1))), dim3(256), 0, (hipStream_t)stream,
+                       c_match, v_t, ref_importance, (int)B, (int)R, (int)h, (int)w, (int)H, (int)W, middle_is_vt, sh, sw);
   return check_launch("tcl_ref_importance");
 }
 

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
       select_taps<W2>(tvv, t, p, q, r, s);
       vr = blend(p, q, r, s, t) > 0.5f ? 1.f : 0.f;
     }
-    a.vo[b * a.vo_sb + f * a.vo_sf + pix] = vr;
+    st_stream(a.vo + b * a.vo_sb + f * a.vo_sf + pix, vr);
   }
   // ---- image channels
   if (C3) {
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
     for (int c = 0; c < 3; ++c) {
       float p, q, r, s;
       select_taps<W2>(tv[c], t, p, q, r, s);
-      op[c * a.xo_sc] = blend(p, q, r, s, t);
+      st_stream(op + c * a.xo_sc, blend(p, q, r, s, t));
     }
   } else if (a.xo) {
     for (int c0 = 0; c0 < a.C; c0 += FWD_MAXC) {
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
         float p, q, r, s;
         select_taps<W2>(tv[c], t, p, q, r, s);
         const float val = blend(p, q, r, s, t);
-        if (c0 + c < a.C) op[(c0 + c) * a.xo_sc] = val;
+        if (c0 + c < a.C) st_stream(op + (c0 + c) * a.xo_sc, val);
       }
     }
   }
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
       if (tid < 6) a.partial[((int64_t)n * gridDim.x + blockIdx.x) * 6 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }
   } else if (a.g_grid) {
-    if (ok) reinterpret_cast<float2 *>(a.g_grid)[(int64_t)n * HW + pix] = make_float2(gix, giy);
+    if (ok) st_stream2(a.g_grid + ((int64_t)n * HW + pix) * 2, gix, giy);
   }
 }
 
@@ -311,8 +311,8 @@ __global__ void __launch_bounds__(256) affine_grid_kernel(const float *__restric
   const int y = p / W, x = p - y * W;
   const float *th = theta + (int64_t)n * 6;
   const float xs = base_coord_step(x, W, stepx, ac), ys = base_coord_step(y, H, stepy, ac);
-  out[(int64_t)n * H * W + p] = make_float2(__fadd_rn(__fadd_rn(__fmul_rn(th[0], xs), __fmul_rn(th[1], ys)), th[2]),
-                                            __fadd_rn(__fadd_rn(__fmul_rn(th[3], xs), __fmul_rn(th[4], ys)), th[5]));
+  st_stream2(reinterpret_cast<float *>(out + (int64_t)n * H * W + p), __fadd_rn(__fadd_rn(__fmul_rn(th[0], xs), __fmul_rn(th[1], ys)), th[2]),
+             __fadd_rn(__fadd_rn(__fmul_rn(th[3], xs), __fmul_rn(th[4], ys)), th[5]));
 }
 
 static inline float lin_step(int64_t n) { return n > 1 ? 2.f / (float)(n - 1) : 0.f; }
