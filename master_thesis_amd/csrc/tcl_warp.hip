@@ -21,7 +21,24 @@ struct WarpArgs {
   int NB, NF, C, H, W;
   int align_corners, v_mode;
   float stepx, stepy;  // 2/(W-1), 2/(H-1) (torch.linspace step), divided on the host
+  int gf;              // frames per XCD unit (see warp_block): NF when the frames of a batch item share one source frame
 };
+
+// Grid (8, chunks per unit, units / 8) -> (image n, 256-pixel chunk).  Workgroups are dealt round-robin over the 8 XCDs in
+// linear order (x fastest), so blockIdx.x IS the XCD: unit u (an image, or all `gf` frames of a batch item when they
+// sample ONE shared source frame) lives on XCD u % 8, which walks the unit's chunks in order.  The taps of neighbouring
+// chunks share source rows and now hit in ONE L2 instead of being fetched by up to eight (align_set fwd 5.7 -> 6.7 TB/s).
+// No integer division in the common gf == 1 case.  Returns false for the padding blocks of the last unit group.
+__device__ __forceinline__ bool warp_block(int nchunk, int gf, int nimg, int &n, int &chunk) {
+  const int unit = blockIdx.z * kNumXCD + blockIdx.x;
+  const int fi = gf == 1 ? 0 : (int)blockIdx.y / nchunk;
+  n = unit * gf + fi;
+  chunk = blockIdx.y - fi * nchunk;
+  return n < nimg;
+}
+static inline dim3 warp_grid(int64_t nchunk, int64_t gf, int64_t nimg) {
+  return dim3(kNumXCD, (unsigned)(nchunk * gf), (unsigned)cdiv(nimg / gf, kNumXCD));
+}
 
 __device__ __forceinline__ float unnormalise(float g, int size, bool align_corners) {
   if (align_corners) return __fmul_rn(__fmul_rn(__fadd_rn(g, 1.f), 0.5f), (float)(size - 1));
@@ -134,9 +151,11 @@ constexpr int FWD_MAXC = 3;             // channels whose taps are fetched toget
 // VMODE and C3 (C == 3, the reference's frames) are template parameters for the same reason.
 template <bool HAS_THETA, bool W2, int VMODE, bool C3>
 __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
-  const int n = blockIdx.y, b = n / a.NF, f = n - b * a.NF;
   const int H = a.H, W = a.W;
-  const int pix = blockIdx.x * 256 + threadIdx.x;   // flattened: every wave reads / writes 256 contiguous, aligned bytes per plane
+  int n, chunk;
+  if (!warp_block((H * W + 255) >> 8, a.gf, a.NB * a.NF, n, chunk)) return;
+  const int b = n / a.NF, f = n - b * a.NF;
+  const int pix = chunk * 256 + threadIdx.x;   // flattened: every wave reads / writes 256 contiguous, aligned bytes per plane
   if (pix >= H * W) return;
   const int y = pix / W, x = pix - y * W;
   const bool ac = a.align_corners != 0;
@@ -221,9 +240,11 @@ struct WarpBwdArgs {
 // HAS_GX adds the scatter-add of the input gradient (float atomics into a zeroed buffer).
 template <bool HAS_THETA, bool HAS_GX, bool W2, bool C3>
 __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
-  const int n = blockIdx.y, b = n / a.NF, f = n - b * a.NF;
-  const int H = a.H, W = a.W, HW = H * W;
-  const int pix0 = blockIdx.x * 256 + threadIdx.x;
+  const int H = a.H, W = a.W, HW = H * W, nchunk = (HW + 255) >> 8;
+  // plain (chunk, image) grid: the XCD-aware order of the forward kernel measured 7 % SLOWER here
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int b = n / a.NF, f = n - b * a.NF;
+  const int pix0 = chunk * 256 + threadIdx.x;
   const bool ok = pix0 < HW;
   const int pix = ok ? pix0 : HW - 1;          // lanes past the image repeat its last pixel; nothing of theirs is stored
   const int y = pix / W, x = pix - y * W;
@@ -277,7 +298,7 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
         if ((tid & 63) == 0) red[tid >> 6][k] = s;
       }
       __syncthreads();
-      if (tid < 6) a.partial[((int64_t)n * gridDim.x + blockIdx.x) * 6 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      if (tid < 6) a.partial[((int64_t)n * nchunk + chunk) * 6 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }
   } else if (a.g_grid) {
     if (ok) st_stream2(a.g_grid + ((int64_t)n * HW + pix) * 2, gix, giy);
@@ -333,11 +354,13 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
   TCL_REQUIRE((x_out == nullptr) || (x != nullptr && C > 0), TCL_ERR_ARG, "tcl_warp_fwd: x_out given without x");
   TCL_REQUIRE(x_out || v_mode != TCL_VMODE_NONE, TCL_ERR_ARG, "tcl_warp_fwd: nothing to compute");
   TCL_REQUIRE(!grid || aligned(grid, 8), TCL_ERR_ARG, "tcl_warp_fwd: grid must be 8-byte aligned");
-  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536, TCL_ERR_SHAPE, "tcl_warp_fwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
+  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536 && cdiv(H * W, 256) * NF < 65536, TCL_ERR_SHAPE,
+              "tcl_warp_fwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   WarpArgs a{x, x_sb, x_sf, x_sc, v, v_sb, v_sf, grid, theta, x_out, xo_sb, xo_sf, xo_sc, v_out, vo_sb, vo_sf,
-             (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H)};
+             (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H),
+             (x_out && x_sf == 0 && (!v || v_sf == 0)) ? (int)NF : 1};
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grd((unsigned)cdiv(H * W, 256), (unsigned)(NB * NF)), blk(256);
+  const dim3 grd = warp_grid(cdiv(H * W, 256), a.gf, NB * NF), blk(256);
   const bool c3 = x_out != nullptr && C == 3;
 #define TCL_LAUNCH_WARP(TH, W2, VM)                                                                  \
   do {                                                                                                \
@@ -387,7 +410,8 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
   TCL_REQUIRE(!(grid && g_theta) && !(theta && g_grid), TCL_ERR_ARG, "tcl_warp_bwd: gradient kind does not match the forward's source");
   TCL_REQUIRE(!grid || aligned(grid, 8), TCL_ERR_ARG, "tcl_warp_bwd: grid must be 8-byte aligned");
   TCL_REQUIRE(!g_grid || aligned(g_grid, 8), TCL_ERR_ARG, "tcl_warp_bwd: g_grid must be 8-byte aligned");
-  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536, TCL_ERR_SHAPE, "tcl_warp_bwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
+  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536, TCL_ERR_SHAPE,
+              "tcl_warp_bwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   if (!g_x && !g_grid && !g_theta) return TCL_OK;
   const int N = (int)(NB * NF);
   const int per = (int)cdiv(H * W, 256);
