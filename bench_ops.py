@@ -63,15 +63,24 @@ def bench_warp(iters):
     npix = B * R * H * W
     ms = timed(lambda: F.align_set(x, v, flow), iters)
     report("align_set fwd 256^2 (C3)", ms, bytes_=npix * (4 * 4 + 8 + 4 * 4), units=B * R, note="read x(3)+v(1)+grid(2), write x(3)+v(1)")
-    flow_g = flow.clone().requires_grad_(True)
-    xa, _ = F.align_set(x, v, flow_g)
-    cot = torch.randn_like(xa)
-    ms = timed(lambda: torch.autograd.grad(xa, flow_g, cot, retain_graph=True), iters)
+    # backward through the C ABI directly (an autograd.grad call costs more host time than these kernels run)
+    import ctypes
+    from master_thesis_amd import _lib
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    xa, _ = F.align_set(x, v, flow)
+    cot = torch.randn_like(xa)          # (B,3,R,H,W) view of a (B,R,3,H,W) buffer, like the forward's output
+    g_grid, g_x = torch.empty_like(flow), torch.zeros_like(x)
+    ws = torch.empty(256, dtype=torch.uint8, device=DEV)
+    def bwd(with_gx):
+        if with_gx:
+            g_x.zero_()
+        _lib.call("tcl_warp_bwd", P(cot), cot.stride(0), cot.stride(2), cot.stride(1), P(x), x.stride(0), x.stride(2), x.stride(1),
+                  P(flow), None, P(g_x) if with_gx else None, g_x.stride(0), g_x.stride(2), g_x.stride(1), P(g_grid), None,
+                  B, R, 3, H, W, 1, P(ws), ws.numel(), None)
+    ms = timed(lambda: bwd(False), iters)
     report("align_set bwd grad-grid only 256^2 (what the reference exercises)", ms, bytes_=npix * (3 * 4 + 3 * 4 + 8 + 8), units=B * R,
            note="read grad_out(3)+x(3)+grid(2), write grad_grid(2)")
-    x_g = x.clone().requires_grad_(True)
-    xa2, _ = F.align_set(x_g, v, flow_g)
-    ms = timed(lambda: torch.autograd.grad(xa2, [x_g, flow_g], cot, retain_graph=True), iters)
+    ms = timed(lambda: bwd(True), iters)
     report("align_set bwd grad-grid + grad-input (atomics) 256^2", ms, bytes_=npix * (3 * 4 + 3 * 4 + 8 + 8 + 3 * 4), units=B * R,
            note="incl. memset of grad_x; atomics bound ~1.3 TB/s of added bytes")
 

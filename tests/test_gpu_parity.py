@@ -412,6 +412,22 @@ def test_context_matching_shape_corners(mods, B, C, R, h, w, variant):
     assert_close(N(g), og, rtol=1e-3, atol=1e-4, what="g_c_feats")
 
 
+@pytest.mark.parametrize("H,W,h,w", [(22, 27, 5, 7), (20, 36, 5, 9), (17, 9, 20, 13), (24, 40, 3, 5)])
+@pytest.mark.parametrize("variant", ["default", "complete"])
+def test_ref_importance_odd_and_vector_widths(mods, H, W, h, w, variant):
+    """ref_importance at widths that take the one-pixel-per-lane kernel (W % 4 != 0) and the four-pixel one, at
+    non-integer mask scales (incl. upscaling)."""
+    rng = np.random.default_rng(H * 100 + W)
+    B, C, R = 2, 4, 3
+    cf = (0.3 * rng.standard_normal((B, C, R + 1, h, w))).astype(np.float32)
+    v_t, v_al = _masks(rng, (B, 1, H, W), 0.6), _masks(rng, (B, 1, R, H, W), 0.7)
+    cls = mods["cpn"].CPNContextMatchingDefault if variant == "default" else mods["cpn"].CPNContextMatchingComplete
+    p_in, c_mask, ref_imp = cls()(T(cf), T(v_t), T(v_al), normalize=True)
+    op, om, oref = O.context_matching(cf, v_t, v_al, True, variant)
+    assert_close(N(p_in), op, what="p_in")
+    assert_close(N(ref_imp), oref, what="ref_importance")
+
+
 # ------------------------------------------------------------------------------------------------ callers of the path (SURVEY §8f N2)
 def _standin_model(flows):
     """A callable with the alignment network's interface that returns fixed flows (the conv stacks are out of scope)."""
