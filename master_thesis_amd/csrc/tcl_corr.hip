@@ -234,6 +234,20 @@ struct TileLoader {
     }
   }
 
+  // Full tiles (M, N multiples of the block tile, K of BK, 16-byte aligned rows): no bounds, no per-load 64-bit index
+  // arithmetic.  `p0` = this thread's first float4 of the operand's k-tile 0 (thread_base); float4 i sits a block-uniform
+  // `i * step(ld)` floats further, the next k-tile `kstep(ld)` floats further.
+  __device__ __forceinline__ static const float *thread_base(const float *base, int64_t ld, int row0, int tid) {
+    if (KC) return base + (int64_t)(row0 + tid / (BK / 4)) * ld + (tid % (BK / 4)) * 4;
+    return base + (int64_t)(tid / (ROWS / 4)) * ld + row0 + (tid % (ROWS / 4)) * 4;
+  }
+  __device__ __forceinline__ static int64_t step(int64_t ld) { return KC ? (NT / (BK / 4)) * ld : (NT / (ROWS / 4)) * ld; }
+  __device__ __forceinline__ static int64_t kstep(int64_t ld) { return KC ? BK : BK * ld; }
+  __device__ __forceinline__ void load_full(const float *p0, int64_t st) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const f32x4 *>(p0 + i * st);
+  }
+
   __device__ __forceinline__ void store(float *lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -264,7 +278,7 @@ __device__ __forceinline__ f32x4 read_frag(const float *lds, int row, int kbase)
 // writes that pair to g.D as float2 at [z][m][n-tile] (the volume itself never reaches HBM).
 enum { EPI_STORE = 0, EPI_ARGMAX = 1 };
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int EPI>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int EPI, bool FULL = false>
 __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -304,16 +318,32 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
   const int ktiles = (g.K + BK - 1) / BK;
   const int total = ktiles * g.nseg;
 
-  la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
-  lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
+  // FULL: per-thread operand cursors, advanced by a block-uniform stride per k-tile (segment change: rewind + a_ss / b_ss)
+  const float *pa = FULL ? la.thread_base(Ab, g.a_ld, m0, tid) : nullptr;
+  const float *pb = FULL ? lb.thread_base(Bb, g.b_ld, n0, tid) : nullptr;
+  const int64_t a_st = la.step(g.a_ld), b_st = lb.step(g.b_ld), a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
+  int kt_next = 1;
+  if (FULL) { la.load_full(pa, a_st); lb.load_full(pb, b_st); }
+  else {
+    la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
+    lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
+  }
   for (int t = 0; t < total; ++t) {
     la.store(As, tid);
     lb.store(Bs, tid);
     __syncthreads();
     if (t + 1 < total) {  // prefetch the next tile while this one is multiplied
-      const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
-      la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BK, g.M, g.K, tid);
-      lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BK, g.N, g.K, tid);
+      if (FULL) {
+        if (kt_next == ktiles) { kt_next = 0; pa += g.a_ss - (ktiles - 1) * a_k; pb += g.b_ss - (ktiles - 1) * b_k; }
+        else { pa += a_k; pb += b_k; }
+        ++kt_next;
+        la.load_full(pa, a_st);
+        lb.load_full(pb, b_st);
+      } else {
+        const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
+        la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BK, g.M, g.K, tid);
+        lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BK, g.N, g.K, tid);
+      }
     }
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
@@ -412,7 +442,14 @@ static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
   const bool vec = aligned(g.A, 16) && aligned(g.B, 16) && g.a_ld % 4 == 0 && g.b_ld % 4 == 0 && g.a_bs % 4 == 0 &&
                    g.b_bs % 4 == 0 && g.a_ss % 4 == 0 && g.b_ss % 4 == 0 && (A_KC ? g.K % 4 == 0 : g.M % 4 == 0) &&
                    (B_KC ? g.K % 4 == 0 : g.N % 4 == 0);
-  if (vec)
+  const bool full = vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0;
+#ifdef TCL_GEMM_NO_FULL
+  if (false)
+#else
+  if (full)
+#endif
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, true, EPI, true>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
+  else if (vec)
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, true, EPI>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
   else
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, false, EPI>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
