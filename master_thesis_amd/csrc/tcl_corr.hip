@@ -248,6 +248,10 @@ struct TileLoader {
     for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const f32x4 *>(p0 + i * st);
   }
 
+  // PW > 0 (k-major tiles only): rows are stored permuted so that the 32-row MFMA blocks of ONE wave lie PW*32 floats
+  // apart: row = w*(ROWS/PW) + i*32 + l  ->  i*(PW*32) + w*32 + l.  With PW = 2 that stride is 64 dwords and a k row is 128,
+  // so every fragment pair of a k-tile is one ds_read2st64_b32 off a single base register.
+  template <int PW = 0>
   __device__ __forceinline__ void store(float *lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -256,7 +260,9 @@ struct TileLoader {
         const int row = idx / (BK / 4), k = (idx % (BK / 4)) * 4;
         *reinterpret_cast<f32x4 *>(lds + row * KC_LD + k) = r[i];
       } else {
-        const int k = idx / (ROWS / 4), row = (idx % (ROWS / 4)) * 4;
+        const int k = idx / (ROWS / 4);
+        int row = (idx % (ROWS / 4)) * 4;
+        if (PW > 0) row = ((row % (ROWS / PW)) / 32) * (PW * 32) + (row / (ROWS / PW)) * 32 + (row & 31);
         *reinterpret_cast<f32x4 *>(lds + k * ROWS + row) = r[i];
       }
     }
@@ -328,9 +334,10 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
     la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
     lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
   }
+  constexpr bool PIPE = !A_KC && !B_KC && EPI == EPI_STORE;   // hand-pipelined fragment reads, permuted LDS rows
   for (int t = 0; t < total; ++t) {
-    la.store(As, tid);
-    lb.store(Bs, tid);
+    la.template store<PIPE ? WM : 0>(As, tid);
+    lb.template store<PIPE ? WN : 0>(Bs, tid);
     __syncthreads();
     if (t + 1 < total) {  // prefetch the next tile while this one is multiplied
       if (FULL) {
@@ -345,6 +352,43 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
         lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BK, g.N, g.K, tid);
       }
     }
+    if (PIPE) {
+      // Both operands k-major: a fragment slice (one k per lane half) is TM + TN scalar LDS reads.  Software-pipelined by
+      // hand: the reads of slice s+1 are issued BEFORE the TM*TN MFMAs of slice s, so the LDS latency hides under 256
+      // cycles of MFMA.  (hipcc on its own sinks every read group next to its use: `ds_read; s_waitcnt lgkmcnt(0);
+      // 4 x mfma`, which leaves the matrix pipe idle for the LDS round trip 16 times per k-tile.)  The
+      // sched_group_barriers pin that order: the DS reads of the next slice, then the MFMAs of this one.
+      constexpr int NSL = BK / 2;   // slices per k-tile
+      float a_cur[TM], b_cur[TN], a_nxt[TM], b_nxt[TN];
+      const float *ap = As + (lh * 4) * BM + (wid / WN) * 32 + lr, *bp = Bs + (lh * 4) * BN + (wid % WN) * 32 + lr;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a_cur[i] = ap[i * (WM * 32)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b_cur[j] = bp[j * (WN * 32)];
+      __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) / 2, 0);       // DS reads of slice 0
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl) {
+        if (sl + 1 < NSL) {
+          const int kk = ((sl + 1) >> 2) * 8 + ((sl + 1) & 3);   // k row of the next slice (this lane half adds lh * 4)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a_nxt[i] = ap[kk * BM + i * (WM * 32)];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b_nxt[j] = bp[kk * BN + j * (WN * 32)];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[j], a_cur[i], acc[i][j], 0, 0, 0);
+        if (sl + 1 < NSL) __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) / 2, 0);   // DS reads of slice sl+1
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                           // MFMAs of slice sl
+        if (sl + 1 < NSL) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
+        }
+      }
+    } else
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
       f32x4 af[TM], bf[TN];
