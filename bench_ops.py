@@ -3,7 +3,7 @@
 and the other correlation variants.  Not the headline bench (that is bench.py); prints one JSON line per op with the
 achieved algorithmic GB/s (or TFLOP/s) against the MI355X peak, timed with HIP events on the launch stream.
 
-    python bench_ops.py [--iters 20] [--ops warp,affine,ctx,corr_model,argmax,movement,sched,cpu]      (cpu = the numpy port on the host cores)
+    python bench_ops.py [--iters 20] [--ops warp,affine,ctx,corr_model,argmax,movement,sched,misc,cpu]      (cpu = the numpy port on the host cores)
 """
 import argparse
 import json
@@ -217,6 +217,24 @@ def bench_sched(iters):
                       "speedup": round(ts / tb, 2), "note": "identical outputs; stand-in networks, so the time is the schedulers' own ops + launches"}), flush=True)
 
 
+def bench_misc(iters):
+    """A5 standalone masked softmax at the C4 shape and A2 per-pixel correlation (both are utilities off the hot loop:
+    the context-matching kernels fuse A5, nothing in the reference calls A2)."""
+    from master_thesis_amd.models import cpn
+    from master_thesis_amd.utils import correlation
+    g = torch.Generator().manual_seed(8)
+    B, C, R, h, w = 32, 128, 10, 30, 53
+    vec = torch.randn(B, C, R, h, w, generator=g).to(DEV)
+    mask = (torch.rand(B, 1, R, h, w, generator=g) < 0.7).float().to(DEV)
+    ms = timed(lambda: cpn.masked_softmax(vec, mask, 2), iters)
+    report("masked_softmax fwd (B,128,10,30,53) (A5 standalone)", ms, bytes_=vec.numel() * 8 + mask.numel() * 4, units=B, unit_name="targets")
+    B, C, H, W = 32, 256, 64, 64
+    f1, f2 = torch.randn(B, C, H, W, generator=g).to(DEV), torch.randn(B, C, H, W, generator=g).to(DEV)
+    m1, m2 = (torch.rand(B, 1, H, W, generator=g) < 0.9).float().to(DEV), (torch.rand(B, 1, H, W, generator=g) < 0.9).float().to(DEV)
+    ms = timed(lambda: correlation.compute_masked_correlation(f1, f2, m1, m2), iters)
+    report("compute_masked_correlation fwd (32,256,64,64) (A2)", ms, bytes_=2 * f1.numel() * 4 + 3 * B * H * W * 4, units=B)
+
+
 def bench_cpu(iters):
     """The CPU restatement of the reference (numpy oracle, `kind: port`) on the host cores, on bounded samples of the same
     workloads: pairs/s beside the GPU rows above (a reported baseline, not a target)."""
@@ -254,7 +272,7 @@ def main():
     ap.add_argument("--ops", default="warp,affine,ctx,corr_model,argmax")
     a = ap.parse_args()
     torch.cuda.set_device(0)
-    table = dict(movement=bench_movement, sched=bench_sched, warp=bench_warp, affine=bench_affine, ctx=bench_ctx, corr_model=bench_corr_model, argmax=bench_argmax, cpu=bench_cpu)
+    table = dict(misc=bench_misc, movement=bench_movement, sched=bench_sched, warp=bench_warp, affine=bench_affine, ctx=bench_ctx, corr_model=bench_corr_model, argmax=bench_argmax, cpu=bench_cpu)
     for op in a.ops.split(","):
         table[op](a.iters)
 

@@ -742,44 +742,72 @@ static CorrWs corr_ws(void *base, int64_t B, int64_t C, int64_t F, int64_t P) {
 }
 
 // ------------------------------------------------------------------------------------------ A2 per-pixel correlation
+// Block = 64 consecutive pixels x 4 waves; wave w reduces the channels c = w, w+4, ... (8 channel pairs of loads in flight
+// per step), the four partial sums are combined through LDS in wave order (deterministic).
+constexpr int C1_U = 8;
+__device__ __forceinline__ void corr1x1_sums(const float *p1, const float *p2, int64_t P, int C, int wv, float a, float c2,
+                                             float (&red)[3][4][64], int lane, float &s1, float &s2, float &d) {
+  float t1s = 0.f, t2s = 0.f, ds = 0.f;
+  for (int c0 = wv; c0 < C; c0 += 4 * C1_U) {
+    float x1[C1_U], x2[C1_U];
+#pragma unroll
+    for (int u = 0; u < C1_U; ++u) {
+      const int c = min(c0 + 4 * u, C - 1);   // clamped, unconditional loads; padding channels are zeroed below
+      x1[u] = p1[(int64_t)c * P];
+      x2[u] = p2[(int64_t)c * P];
+    }
+    TCL_LOADS_FIRST(2 * C1_U);
+#pragma unroll
+    for (int u = 0; u < C1_U; ++u) {
+      const float live = c0 + 4 * u < C ? 1.f : 0.f;
+      const float t1 = x1[u] * a * live, t2 = x2[u] * c2 * live;
+      t1s += t1 * t1; t2s += t2 * t2; ds += t1 * t2;
+    }
+  }
+  red[0][wv][lane] = t1s; red[1][wv][lane] = t2s; red[2][wv][lane] = ds;
+  __syncthreads();
+  s1 = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+  s2 = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+  d = (red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]);
+}
+
 __global__ void __launch_bounds__(256) corr1x1_fwd_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
                                                           const float *__restrict__ m1, const float *__restrict__ m2,
                                                           float *__restrict__ out, int C, int P, int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = i / P, p = i - b * P;
-    const float a = m1[i], c2 = m2[i];
-    const float *p1 = f1 + b * C * P + p, *p2 = f2 + b * C * P + p;
-    float s1 = 0.f, s2 = 0.f, d = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float t1 = p1[(int64_t)c * P] * a, t2 = p2[(int64_t)c * P] * c2;
-      s1 += t1 * t1; s2 += t2 * t2; d += t1 * t2;
-    }
-    out[i] = d / ((sqrtf(s1) + kNormEps) * (sqrtf(s2) + kNormEps));
-  }
+  __shared__ float red[3][4][64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
+  const bool ok = i0 < total;
+  const int64_t i = ok ? i0 : total - 1;
+  const int64_t b = i / P, p = i - b * P;
+  float s1, s2, d;
+  corr1x1_sums(f1 + b * C * P + p, f2 + b * C * P + p, P, C, wv, m1[i], m2[i], red, lane, s1, s2, d);
+  if (ok && wv == 0) out[i] = d / ((sqrtf(s1) + kNormEps) * (sqrtf(s2) + kNormEps));
 }
 
 __global__ void __launch_bounds__(256) corr1x1_bwd_kernel(const float *__restrict__ go, const float *__restrict__ f1,
                                                           const float *__restrict__ f2, const float *__restrict__ m1,
                                                           const float *__restrict__ m2, float *__restrict__ g1,
                                                           float *__restrict__ g2, int C, int P, int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = i / P, p = i - b * P;
-    const float a = m1[i], c2 = m2[i], g = go[i];
-    const float *p1 = f1 + b * C * P + p, *p2 = f2 + b * C * P + p;
-    float s1 = 0.f, s2 = 0.f, d = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float t1 = p1[(int64_t)c * P] * a, t2 = p2[(int64_t)c * P] * c2;
-      s1 += t1 * t1; s2 += t2 * t2; d += t1 * t2;
-    }
-    const float n1 = sqrtf(s1), n2 = sqrtf(s2), e1 = n1 + kNormEps, e2 = n2 + kNormEps;
-    // d_a1^ = g a2^ ; <d_a1^, t1> = g d / e2  (and symmetrically)
-    const float k1 = n1 > 0.f ? (g * d / e2) / (e1 * e1 * n1) : 0.f;
-    const float k2 = n2 > 0.f ? (g * d / e1) / (e2 * e2 * n2) : 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float t1 = p1[(int64_t)c * P] * a, t2 = p2[(int64_t)c * P] * c2;
-      if (g1) g1[b * C * P + (int64_t)c * P + p] = (g * (t2 / e2) / e1 - t1 * k1) * a;
-      if (g2) g2[b * C * P + (int64_t)c * P + p] = (g * (t1 / e1) / e2 - t2 * k2) * c2;
-    }
+  __shared__ float red[3][4][64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
+  const bool ok = i0 < total;
+  const int64_t i = ok ? i0 : total - 1;
+  const int64_t b = i / P, p = i - b * P;
+  const float a = m1[i], c2 = m2[i], g = go[i];
+  const float *p1 = f1 + b * C * P + p, *p2 = f2 + b * C * P + p;
+  float s1, s2, d;
+  corr1x1_sums(p1, p2, P, C, wv, a, c2, red, lane, s1, s2, d);
+  const float n1 = sqrtf(s1), n2 = sqrtf(s2), e1 = n1 + kNormEps, e2 = n2 + kNormEps;
+  // d_a1^ = g a2^ ; <d_a1^, t1> = g d / e2  (and symmetrically)
+  const float k1 = n1 > 0.f ? (g * d / e2) / (e1 * e1 * n1) : 0.f;
+  const float k2 = n2 > 0.f ? (g * d / e1) / (e2 * e2 * n2) : 0.f;
+  if (!ok) return;
+  for (int c = wv; c < C; c += 4) {   // second pass over the wave's channels (L2-resident by now)
+    const float t1 = p1[(int64_t)c * P] * a, t2 = p2[(int64_t)c * P] * c2;
+    if (g1) g1[b * C * P + (int64_t)c * P + p] = (g * (t2 / e2) / e1 - t1 * k1) * a;
+    if (g2) g2[b * C * P + (int64_t)c * P + p] = (g * (t1 / e1) / e2 - t2 * k2) * c2;
   }
 }
 
@@ -999,8 +1027,8 @@ extern "C" int tcl_corr1x1_fwd(const float *f1, const float *f2, const float *m1
                                int64_t C, int64_t P, void *stream) {
   TCL_REQUIRE(B > 0 && C > 0 && P > 0 && P < (1LL << 31) && C < (1 << 24), TCL_ERR_SHAPE, "tcl_corr1x1_fwd: bad shape");
   TCL_REQUIRE(f1 && f2 && m1 && m2 && out, TCL_ERR_ARG, "tcl_corr1x1_fwd: NULL pointer");
-  int64_t blocks = cdiv(B * P, 256);
-  if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+  const int64_t blocks = cdiv(B * P, 64);
+  TCL_REQUIRE(blocks < (1LL << 31), TCL_ERR_SHAPE, "tcl_corr1x1_fwd: too many pixels for one launch");
   hipLaunchKernelGGL(corr1x1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f1, f2, m1, m2, out, (int)C, (int)P, B * P);
   return check_launch("tcl_corr1x1_fwd");
 }
@@ -1010,8 +1038,8 @@ extern "C" int tcl_corr1x1_bwd(const float *grad_out, const float *f1, const flo
   TCL_REQUIRE(B > 0 && C > 0 && P > 0 && P < (1LL << 31) && C < (1 << 24), TCL_ERR_SHAPE, "tcl_corr1x1_bwd: bad shape");
   TCL_REQUIRE(grad_out && f1 && f2 && m1 && m2, TCL_ERR_ARG, "tcl_corr1x1_bwd: NULL pointer");
   if (!g_f1 && !g_f2) return TCL_OK;
-  int64_t blocks = cdiv(B * P, 256);
-  if (blocks > kMaxStreamBlocks) blocks = kMaxStreamBlocks;
+  const int64_t blocks = cdiv(B * P, 64);
+  TCL_REQUIRE(blocks < (1LL << 31), TCL_ERR_SHAPE, "tcl_corr1x1_bwd: too many pixels for one launch");
   hipLaunchKernelGGL(corr1x1_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad_out, f1, f2, m1, m2, g_f1, g_f2, (int)C, (int)P, B * P);
   return check_launch("tcl_corr1x1_bwd");
 }

@@ -137,6 +137,70 @@ __global__ void __launch_bounds__(256) masked_softmax_fwd_kernel(const float *__
   }
 }
 
+// R <= 16 (the reference's use: R = reference frames): one (o,i) per lane, all 2R (3R) loads of the lane in flight
+// before the first use, values kept in registers, outputs written once as streaming stores.  Same arithmetic, same
+// operation order as the generic kernels above / below.
+template <int R>
+__global__ void __launch_bounds__(256) masked_softmax_fwd_small_kernel(const float *__restrict__ vec, const float *__restrict__ mask,
+                                                                       float *__restrict__ out, int64_t O, int64_t Om, int64_t I) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= O * I) return;
+  const int64_t o = t / I, i = t - o * I;
+  const float *vp = vec + o * R * I + i, *mp = mask + (o / (O / Om)) * R * I + i;
+  float v[R], m[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { v[r] = vp[r * I]; m[r] = mp[r * I]; }
+  TCL_LOADS_FIRST(2 * R);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < R; ++r) mx = fmaxf(mx, v[r] * m[r]);
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) { v[r] = expf(v[r] * m[r] - mx) * m[r]; s += v[r]; }
+  if (s < 1e-4f) s += 1.f;
+  float *op = out + o * R * I + i;
+#pragma unroll
+  for (int r = 0; r < R; ++r) st_stream(op + r * I, v[r] / s);
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) masked_softmax_bwd_small_kernel(const float *__restrict__ go, const float *__restrict__ vec,
+                                                                       const float *__restrict__ mask, float *__restrict__ gv,
+                                                                       int64_t O, int64_t Om, int64_t I) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= O * I) return;
+  const int64_t o = t / I, i = t - o * I;
+  const float *vp = vec + o * R * I + i, *mp = mask + (o / (O / Om)) * R * I + i, *gp = go + o * R * I + i;
+  float v[R], m[R], g[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { v[r] = vp[r * I]; m[r] = mp[r * I]; g[r] = gp[r * I]; }
+  TCL_LOADS_FIRST(3 * R);
+  float mx = -INFINITY;
+  int am = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float z = v[r] * m[r];
+    if (z > mx) { mx = z; am = r; }
+  }
+  float s = 0.f, ge = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    v[r] = expf(v[r] * m[r] - mx) * m[r];   // e_r
+    s += v[r];
+    ge += g[r] * v[r];
+  }
+  const float sp = s < 1e-4f ? s + 1.f : s;
+  float tot = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    g[r] = (g[r] / sp - ge / (sp * sp)) * v[r];   // d_r before the max term
+    tot += g[r];
+  }
+  float *op = gv + o * R * I + i;
+#pragma unroll
+  for (int r = 0; r < R; ++r) st_stream(op + r * I, (r == am ? g[r] - tot : g[r]) * m[r]);
+}
+
 __global__ void __launch_bounds__(256) masked_softmax_bwd_kernel(const float *__restrict__ go, const float *__restrict__ vec,
                                                                  const float *__restrict__ mask, float *__restrict__ gv,
                                                                  int64_t O, int64_t Om, int R, int64_t I) {
@@ -632,14 +696,34 @@ extern "C" int tcl_ref_importance(const float *c_match, const float *v_t, float 
 extern "C" int tcl_masked_softmax_fwd(const float *vec, const float *mask, float *out, int64_t O, int64_t Om, int64_t R, int64_t I, void *stream) {
   TCL_REQUIRE(O > 0 && Om > 0 && R > 0 && I > 0 && O % Om == 0 && R < (1 << 20), TCL_ERR_SHAPE, "tcl_masked_softmax_fwd: bad shape O=%ld Om=%ld R=%ld I=%ld", (long)O, (long)Om, (long)R, (long)I);
   TCL_REQUIRE(vec && mask && out, TCL_ERR_ARG, "tcl_masked_softmax_fwd: NULL pointer");
-  hipLaunchKernelGGL(masked_softmax_fwd_kernel, dim3(stream_blocks(O * I)), dim3(256), 0, (hipStream_t)stream, vec, mask, out, O, Om, (int)R, I);
+  const dim3 grd((unsigned)cdiv(O * I, 256)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+#define TCL_MSM(RR) case RR: hipLaunchKernelGGL(masked_softmax_fwd_small_kernel<RR>, grd, blk, 0, s, vec, mask, out, O, Om, I); break;
+  if (R <= 16 && cdiv(O * I, 256) < (1LL << 31)) {
+    switch ((int)R) {
+      TCL_MSM(1) TCL_MSM(2) TCL_MSM(3) TCL_MSM(4) TCL_MSM(5) TCL_MSM(6) TCL_MSM(7) TCL_MSM(8)
+      TCL_MSM(9) TCL_MSM(10) TCL_MSM(11) TCL_MSM(12) TCL_MSM(13) TCL_MSM(14) TCL_MSM(15) TCL_MSM(16)
+    }
+  } else
+    hipLaunchKernelGGL(masked_softmax_fwd_kernel, dim3(stream_blocks(O * I)), dim3(256), 0, s, vec, mask, out, O, Om, (int)R, I);
+#undef TCL_MSM
   return check_launch("tcl_masked_softmax_fwd");
 }
 
 extern "C" int tcl_masked_softmax_bwd(const float *grad_out, const float *vec, const float *mask, float *g_vec, int64_t O, int64_t Om, int64_t R, int64_t I, void *stream) {
   TCL_REQUIRE(O > 0 && Om > 0 && R > 0 && I > 0 && O % Om == 0 && R < (1 << 20), TCL_ERR_SHAPE, "tcl_masked_softmax_bwd: bad shape");
   TCL_REQUIRE(grad_out && vec && mask && g_vec, TCL_ERR_ARG, "tcl_masked_softmax_bwd: NULL pointer");
-  hipLaunchKernelGGL(masked_softmax_bwd_kernel, dim3(stream_blocks(O * I)), dim3(256), 0, (hipStream_t)stream, grad_out, vec, mask, g_vec, O, Om, (int)R, I);
+  const dim3 grd((unsigned)cdiv(O * I, 256)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+#define TCL_MSM(RR) case RR: hipLaunchKernelGGL(masked_softmax_bwd_small_kernel<RR>, grd, blk, 0, s, grad_out, vec, mask, g_vec, O, Om, I); break;
+  if (R <= 16 && cdiv(O * I, 256) < (1LL << 31)) {
+    switch ((int)R) {
+      TCL_MSM(1) TCL_MSM(2) TCL_MSM(3) TCL_MSM(4) TCL_MSM(5) TCL_MSM(6) TCL_MSM(7) TCL_MSM(8)
+      TCL_MSM(9) TCL_MSM(10) TCL_MSM(11) TCL_MSM(12) TCL_MSM(13) TCL_MSM(14) TCL_MSM(15) TCL_MSM(16)
+    }
+  } else
+    hipLaunchKernelGGL(masked_softmax_bwd_kernel, dim3(stream_blocks(O * I)), dim3(256), 0, s, grad_out, vec, mask, g_vec, O, Om, (int)R, I);
+#undef TCL_MSM
   return check_launch("tcl_masked_softmax_bwd");
 }
 

@@ -412,6 +412,39 @@ def test_context_matching_shape_corners(mods, B, C, R, h, w, variant):
     assert_close(N(g), og, rtol=1e-3, atol=1e-4, what="g_c_feats")
 
 
+@pytest.mark.parametrize("shape,dim", [((2, 3, 20, 5, 7), 2), ((3, 16, 33), 1), ((2, 1, 4, 9), 0), ((1, 5, 17, 3, 3), 2)])
+def test_masked_softmax_vs_oracle_all_paths(mods, shape, dim):
+    """R > 16 takes the generic kernel, R <= 16 the register-resident one; dim / broadcast layouts other than the reference's."""
+    rng = np.random.default_rng(sum(shape) + dim)
+    vec = (3 * rng.standard_normal(shape)).astype(np.float32)
+    mshape = list(shape)
+    if len(shape) == 5:
+        mshape[1] = 1
+    mask = _masks(rng, tuple(mshape), 0.6)
+    tv = T(vec, True)
+    out = mods["cpn"].masked_softmax(tv, T(mask), dim)
+    assert_close(N(out), O.masked_softmax(vec, mask, dim), what="masked_softmax")
+    cot = rng.standard_normal(shape).astype(np.float32)
+    (g,) = torch.autograd.grad((out * T(cot)).sum(), [tv])
+    assert_close(N(g), O.masked_softmax_bwd(vec, mask, dim, cot), what="masked_softmax bwd")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 130, 9, 13), (1, 2, 5, 5), (3, 37, 8, 8), (1, 64, 1, 100)])
+def test_corr1x1_vs_oracle_ragged(mods, B, C, H, W):
+    """Channel counts that do not divide over the four waves / the unroll, pixel counts that are not multiples of 64."""
+    rng = np.random.default_rng(B * 1000 + C)
+    f1, f2 = rng.standard_normal((B, C, H, W)).astype(np.float32), rng.standard_normal((B, C, H, W)).astype(np.float32)
+    m1, m2 = _masks(rng, (B, 1, H, W), 0.8), _masks(rng, (B, 1, H, W), 0.8)
+    t1, t2 = T(f1, True), T(f2, True)
+    out = mods["corr"].compute_masked_correlation(t1, t2, T(m1), T(m2))
+    assert_close(N(out), O.compute_masked_correlation(f1, f2, m1, m2), what="corr1x1 fwd")
+    cot = rng.standard_normal((B, 1, H, W)).astype(np.float32)
+    g1, g2 = torch.autograd.grad((out * T(cot)).sum(), [t1, t2])
+    o1, o2 = O.compute_masked_correlation_bwd(f1, f2, m1, m2, cot)
+    assert_close(N(g1), o1, what="corr1x1 g1")
+    assert_close(N(g2), o2, what="corr1x1 g2")
+
+
 @pytest.mark.parametrize("H,W,h,w", [(22, 27, 5, 7), (20, 36, 5, 9), (17, 9, 20, 13), (24, 40, 3, 5)])
 @pytest.mark.parametrize("variant", ["default", "complete"])
 def test_ref_importance_odd_and_vector_widths(mods, H, W, h, w, variant):
