@@ -118,11 +118,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # rehearsal switch (not used by the driver): TCL_BENCH_REHEARSE=1 runs every rank on GPU 0 with gloo for the barrier /
+    # max-over-ranks, so the N > 1 code path can be exercised on a one-GPU box
+    rehearse = os.environ.get("TCL_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from master_thesis_amd.utils import correlation
 
@@ -150,7 +158,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
