@@ -261,6 +261,26 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
   sample_pos<HAS_THETA>(a.grid, a.theta, n, y, x, H, W, a.stepx, a.stepy, ac, ix, iy, xs, ys);
   const Taps t = make_taps(ix, iy, H, W);
   float gix = 0.f, giy = 0.f;
+  // Input gradient: neighbouring output pixels of a smooth flow hit neighbouring source columns, so lane l's EAST taps and
+  // lane l+1's WEST taps are usually the same two addresses.  When they are (same rows, column + 1, same validity), lane
+  // l hands its east contributions to lane l+1, which adds them to its west ones: two float atomics per channel and pixel
+  // instead of four.  Both lanes evaluate the same predicate on the same pair of tap descriptors.
+  bool hand_east = false, take_west = false;
+  if (HAS_GX) {
+    const int key = ok ? ((t.xi & 0x3fff) | ((t.yi & 0x3fff) << 14) | (t.yn ? 1 << 28 : 0) | (t.ys ? 1 << 29 : 0)) : -1;
+    const int kx = ok ? ((t.xw ? 1 : 0) | (t.xe ? 2 : 0)) : 0;
+    const int lane = threadIdx.x & 63;
+    const int key_up = __shfl_up(key, 1, 64), kx_up = __shfl_up(kx, 1, 64);       // lane - 1
+    const int key_dn = __shfl_down(key, 1, 64), kx_dn = __shfl_down(kx, 1, 64);   // lane + 1
+    // pair (p, q = p + 1): rows and row validity equal, xi_q == xi_p + 1 (no wrap at 14 bits: W < 16384 on this path),
+    // east of p valid exactly when west of q is
+    auto pair_ok = [](int kp, int xp, int kq, int xq) {
+      return kp != -1 && kq != -1 && (kq - kp) == 1 && ((kp & 0x3fff) != 0x3fff) && (((xp >> 1) & 1) == (xq & 1));
+    };
+    const bool small = (W < 16384) & (H < 16384);   // the 14-bit key fields
+    hand_east = small && lane < 63 && pair_ok(key, kx, key_dn, kx_dn);
+    take_west = small && lane > 0 && pair_ok(key_up, kx_up, key, kx);
+  }
   const int C = C3 ? 3 : a.C;   // C3: the reference's frames; the loop below then is one straight-line pass
   for (int c0 = 0; c0 < C; c0 += FWD_MAXC) {
     float g[FWD_MAXC];
@@ -279,12 +299,18 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
       gix += gc * ((vne - vnw) * t.sy + (vse - vsw) * t.ny);
       giy += gc * ((vsw - vnw) * t.ex + (vse - vne) * t.wx);
       if (HAS_GX) {
+        float cnw = gc * t.nw, csw = gc * t.sw;
+        const float cne = gc * t.ne, cse = gc * t.se;
+        const float ne_up = __shfl_up(cne, 1, 64), se_up = __shfl_up(cse, 1, 64);   // all lanes take part in the shuffles
+        if (take_west) { cnw += ne_up; csw += se_up; }
         if (ok & (c0 + c < C)) {
           float *gplane = a.gx + b * a.gx_sb + f * a.gx_sf + (c0 + c) * a.gx_sc + t.yi * W + t.xi;
-          if (t.xw & t.yn) atomicAdd(gplane, gc * t.nw);
-          if (t.xe & t.yn) atomicAdd(gplane + 1, gc * t.ne);
-          if (t.xw & t.ys) atomicAdd(gplane + W, gc * t.sw);
-          if (t.xe & t.ys) atomicAdd(gplane + W + 1, gc * t.se);
+          if (t.xw & t.yn) atomicAdd(gplane, cnw);
+          if (t.xw & t.ys) atomicAdd(gplane + W, csw);
+          if (!hand_east) {
+            if (t.xe & t.yn) atomicAdd(gplane + 1, cne);
+            if (t.xe & t.ys) atomicAdd(gplane + W + 1, cse);
+          }
         }
       }
     }
