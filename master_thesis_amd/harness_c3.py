@@ -1,0 +1,239 @@
+"""Harness for BASELINE.json configs[0] / configs[2] (C1 / C3): the dense-flow alignment network's step around the HIP hot path.
+
+Only the hot path is this package's product; the network exists here so that the configuration can run end to end and
+the share of the hot path in a real step can be measured:
+
+  feature extractor -> `FeatureStandIn`: a seeded conv stack with VGG-16's stride (256 px -> 16 x 16 x 512).  The reference
+                       uses pretrained VGG-16 weights (models/vgg_16.py) that are not available offline; SURVEY.md §8d
+                       prescribes the seeded stand-in.
+  cost volume       -> `utils.correlation.compute_masked_4d_correlation` on the HIP kernels (A1), 16 x 16 x 512
+  the network       -> `AlignmentNet`: the layer structure of ThesisAlignmentModel (models/thesis_alignment.py:8-225:
+                       separable 4-D convolution over the volume, correlation mixer, two flow estimators) restated on stock
+                       torch convolutions (MIOpen); bf16 autocast for them in C3, the volume and the warps stay fp32
+  after the network -> `runners.train_step_propagate`: six `align_set` warps at 16 / 64 / 256 px, two `resize_flow`s, `v_map`s
+  loss              -> `alignment_loss`: the terms of ThesisAlignmentRunner.compute_loss (thesis_dfpn/runner.py:161-206)
+
+Run:  python -m master_thesis_amd.harness_c3 --sequences 32 --bf16          (C3, 1 GPU: 128 pairs per step)
+      python -m master_thesis_amd.harness_c3 --sequences 1 --forward-only    (C1's shape on the GPU)
+      python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 -m master_thesis_amd.harness_c3 --sequences 256 --bf16
+"""
+import argparse
+import json
+import os
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import runners
+from .utils import correlation
+from .utils.losses import LossesUtils
+
+
+def conv_stack(spec, in_c, final_relu=True):
+    """spec: list of (out_c, kernel, stride) | ('T', out_c, kernel) for a stride-2 transposed convolution."""
+    layers, c = [], in_c
+    for item in spec:
+        if item[0] == 'T':
+            _, oc, k = item
+            layers.append(nn.ConvTranspose2d(c, oc, k, stride=2, padding=k // 2, output_padding=1))
+        else:
+            oc, k, st = item
+            layers.append(nn.Conv2d(c, oc, k, stride=st, padding=k // 2))
+        layers.append(nn.ReLU())
+        c = oc
+    if not final_relu:
+        layers.pop()
+    return nn.Sequential(*layers)
+
+
+class FeatureStandIn(nn.Module):
+    """(N,3,256,256) -> [.., .., .., (N,512,16,16)] like the VGG wrapper's fourth feature level (stride 16)."""
+
+    def __init__(self):
+        super().__init__()
+        self.body = conv_stack([(64, 3, 2), (128, 3, 2), (256, 3, 2), (512, 3, 2)], 3)
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, x, normalize_input=False):
+        return [None, None, None, self.body(x)]
+
+
+class SeparableConv4d(nn.Module):
+    """Two 2-D conv stacks over a (b,t,h,w,h,w) volume: first over the reference-pixel plane of every target pixel, then
+    over the target-pixel plane of every reference pixel.  models/thesis_alignment.py:8-36."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv_1 = conv_stack([(128, 3, 1), (256, 3, 1), (256, 3, 1)], 1, final_relu=False)
+        self.conv_2 = conv_stack([(256, 3, 1), (128, 3, 1), (1, 3, 1)], 256, final_relu=False)
+
+    def forward(self, corr):
+        b, t, h, w = corr.shape[:4]
+        x = self.conv_1(corr.reshape(b * t * h * w, 1, h, w))                       # per target pixel, over reference pixels
+        x = x.reshape(b, t, h * w, x.size(1), h * w).permute(0, 1, 4, 3, 2)         # -> per reference pixel, over target pixels
+        x = self.conv_2(x.reshape(b * t * h * w, x.size(3), h, w))
+        return x.reshape(b, t, h, w, h, w).permute(0, 1, 4, 5, 2, 3)
+
+
+class AlignmentNet(nn.Module):
+    """model(x_target, m_target, x_refs, m_refs) -> (corr, flow_16, flow_64, flow_256).  models/thesis_alignment.py:166-225."""
+    MIXER = [(256, 5, 1), (256, 3, 1), (16, 3, 1), (16, 5, 1), (16, 3, 1), (8, 3, 1), (8, 5, 1), (8, 3, 1), (4, 3, 1), (4, 5, 1), (4, 3, 1)]
+    FLOW = [(128, 5, 1), (128, 3, 1), (128, 5, 2), (128, 5, 1), (128, 3, 1), (128, 3, 2), (128, 5, 1), (128, 3, 1), (128, 3, 2), (128, 5, 1),
+            (128, 3, 1), ('T', 128, 3), (128, 5, 1), (128, 3, 1), ('T', 128, 3), (128, 5, 1), (128, 3, 1), ('T', 128, 5), (128, 5, 1), (128, 3, 1)]
+
+    def __init__(self, features):
+        super().__init__()
+        self.features = features
+        self.conv4d = SeparableConv4d()
+        self.mixer = nn.Sequential(conv_stack(self.MIXER, 256), nn.Conv2d(4, 2, 3, padding=1), nn.Conv2d(2, 2, 5, padding=2), nn.Conv2d(2, 2, 3, padding=1))
+        self.flow_64 = nn.Sequential(conv_stack(self.FLOW, 10), nn.Conv2d(128, 2, 3, padding=1))
+        self.flow_256 = nn.Sequential(conv_stack(self.FLOW, 10), nn.Conv2d(128, 2, 3, padding=1))
+        self.register_buffer('mean', torch.as_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1, 1))
+        self.register_buffer('std', torch.as_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1, 1))
+
+    @staticmethod
+    def resize_data(x_target, m_target, x_ref, m_ref, size):
+        b, c, r, h, w = x_ref.size()
+        if (h, w) == (size, size):
+            return x_target, m_target, x_ref, m_ref
+        frames = lambda t, mode: F.interpolate(t.transpose(1, 2).reshape(b * r, t.size(1), h, w), (size, size), mode=mode) \
+            .reshape(b, r, t.size(1), size, size).transpose(1, 2)
+        return (F.interpolate(x_target, (size, size), mode='bilinear'), F.interpolate(m_target, (size, size), mode='nearest'),
+                frames(x_ref, 'bilinear'), frames(m_ref, 'nearest'))
+
+    @staticmethod
+    def resize_flow_bilinear(flow, h_new, w_new):
+        b, r, h, w, _ = flow.size()
+        return F.interpolate(flow.reshape(b * r, h, w, 2).permute(0, 3, 1, 2).float(), (h_new, w_new), mode='bilinear') \
+            .reshape(b, r, 2, h_new, w_new).permute(0, 1, 3, 4, 2)
+
+    def estimate(self, net, x_target, m_target, x_ref, m_ref, flow_pre):
+        b, c, r, h, w = x_ref.size()
+        rep = lambda t: t.unsqueeze(1).expand(b, r, t.size(1), h, w).reshape(b * r, t.size(1), h, w)
+        per = lambda t: t.transpose(1, 2).reshape(b * r, t.size(1), h, w)
+        inp = torch.cat([per(x_ref), rep(x_target), per(m_ref), rep(m_target), flow_pre.reshape(b * r, h, w, 2).permute(0, 3, 1, 2)], dim=1)
+        return net(inp).float().reshape(b, r, 2, h, w).permute(0, 1, 3, 4, 2)   # flows leave the autocast region as fp32
+
+    def forward(self, x_target, m_target, x_refs, m_refs):
+        b, c, r, h, w = x_refs.size()
+        x_target = (x_target - self.mean.squeeze(2)) / self.std.squeeze(2)
+        x_refs = (x_refs - self.mean) / self.std
+        xt_sq, mt_sq, xr_sq, mr_sq = self.resize_data(x_target, m_target, x_refs, m_refs, 256)
+        with torch.no_grad():
+            ft = self.features(xt_sq)[3]
+            fr = self.features(xr_sq.transpose(1, 2).reshape(b * r, c, 256, 256))[3]
+        fr = fr.reshape(b, r, -1, 16, 16).transpose(1, 2)
+        v_t = F.interpolate(1 - mt_sq, size=(16, 16), mode='nearest')
+        v_r = F.interpolate(1 - mr_sq.transpose(1, 2).reshape(b * r, 1, 256, 256), size=(16, 16), mode='nearest').reshape(b, r, 1, 16, 16).transpose(1, 2)
+        corr = correlation.compute_masked_4d_correlation(ft.float(), v_t.float(), fr.float(), v_r.float())   # the HIP cost volume, fp32
+        corr = self.conv4d(corr)
+        flow_16 = self.mixer(corr.reshape(b * r, 256, 16, 16)).float().reshape(b, r, 2, 16, 16).permute(0, 1, 3, 4, 2)
+        xt_64, mt_64, xr_64, mr_64 = self.resize_data(x_target, m_target, x_refs, m_refs, 64)
+        flow_64 = self.estimate(self.flow_64, xt_64, mt_64, xr_64, mr_64, self.resize_flow_bilinear(flow_16, 64, 64))
+        flow_256 = self.estimate(self.flow_256, xt_sq, mt_sq, xr_sq, mr_sq, self.resize_flow_bilinear(flow_64, 256, 256))
+        return corr, flow_16, flow_64, self.resize_flow_bilinear(flow_256, h, w)
+
+
+def alignment_loss(features, losses, corr, xs, vs, ys, xs_aligned, flows, flows_gt, flows_use, t, r_list):
+    """Correlation L1 against the volume of the ground-truth frames, three flow L1 terms, two masked reconstruction terms.
+    thesis_dfpn/runner.py:161-206."""
+    b, c, f, h, w = ys[2].size()
+    with torch.no_grad():
+        y_in = ys[2].transpose(1, 2).reshape(b * f, c, h, w)
+        if (h, w) != (256, 256):
+            y_in = F.interpolate(y_in, (256, 256), mode='bilinear')
+        y_feats = features(y_in)[3].float().reshape(b, f, -1, 16, 16).transpose(1, 2)
+        corr_y = correlation.compute_masked_4d_correlation(y_feats[:, :, t], None, y_feats[:, :, r_list], None)
+    items = [F.l1_loss(corr.float(), corr_y)]
+    for k in range(3):
+        items.append(losses.masked_l1(flows[k].float(), flows_gt[k], torch.ones_like(flows_gt[k]), flows_use))
+    for k in (1, 2):
+        outside = ((flows[k] < -1).float() + (flows[k] > 1).float()).sum(4).clamp(0, 1).unsqueeze(1)
+        target = xs[k][:, :, t].unsqueeze(2).expand_as(xs_aligned[k])
+        items.append(losses.masked_l1(target, xs_aligned[k], vs[k][:, :, t].unsqueeze(2) * (1 - outside), reduction='sum'))
+    return sum(items), items
+
+
+def main():
+    import torch.distributed as dist
+
+    from . import parallel
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sequences", type=int, default=8, help="sequences of the whole job per step (C3: 32 per GPU)")
+    ap.add_argument("--micro-batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--bf16", action="store_true", help="bf16 autocast for the stock convolutions (C3)")
+    ap.add_argument("--forward-only", action="store_true", help="C1: the forward of the network + runner step, no loss / backward")
+    args = ap.parse_args()
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    lo, hi = parallel.partition(args.sequences, world, rank)
+    n, S, frames = hi - lo, 256, 5
+    t, r_list = 2, [0, 1, 3, 4]
+    g = torch.Generator().manual_seed(4321 + rank)
+    y = torch.rand(n, 3, frames, S, S, generator=g).to(dev)
+    m = (torch.rand(n, 1, frames, S // 16, S // 16, generator=g) < 0.1).float().repeat_interleave(16, 3).repeat_interleave(16, 4).to(dev)
+    x = (1 - m) * y + m * torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1, 1)
+    ys_, xs_ = torch.meshgrid(torch.linspace(-1, 1, S), torch.linspace(-1, 1, S), indexing="ij")
+    ident = torch.stack([xs_, ys_], -1).to(dev)
+    flow_gt = (ident[None, None] * 1.02 + 0.03 * torch.randn(n, frames, 1, 1, 2, generator=g).to(dev)).contiguous()
+    flows_use = torch.ones(n, dtype=torch.bool, device=dev)
+
+    torch.manual_seed(0)
+    features = FeatureStandIn().to(dev)
+    net = AlignmentNet(features).to(dev)
+    params = [p for p in net.parameters() if p.requires_grad]
+    buckets = parallel.GradientBuckets(params)
+    opt = torch.optim.Adam(params, lr=1e-4)
+    losses = LossesUtils(None, dev)
+    hot = {"ms": 0.0}
+
+    def one(sl):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16):
+            out = runners.train_step_propagate(net, x[sl], m[sl], y[sl], flow_gt[sl], flows_use[sl], t, r_list)
+        if args.forward_only:
+            return out[0].float().mean()
+        corr, xs, vs, ys, xs_al, _, _, _, flows, flows_gt, use, _, _ = out
+        loss, _ = alignment_loss(features, losses, corr, xs, vs, ys, xs_al, flows, flows_gt, use, t, r_list)
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        buckets.reduce().wait()
+        opt.step()
+        return loss.detach()
+
+    def step():
+        for i in range(0, n, args.micro_batch):
+            loss = one(slice(i, min(i + args.micro_batch, n)))
+        return loss
+
+    ctx = torch.no_grad() if args.forward_only else torch.enable_grad()
+    with ctx:
+        step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"workload": "C1: alignment network forward" if args.forward_only else "C3: alignment network training step",
+                          "n_gpus": world, "sequences_per_step": args.sequences, "convs": "bf16 autocast" if args.bf16 else "fp32",
+                          "pairs_per_s": round(args.sequences * len(r_list) * args.steps / el, 2), "ms_per_step": round(el / args.steps * 1e3, 2),
+                          "parameters": sum(p.numel() for p in params), "loss": float(loss)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

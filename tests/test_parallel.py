@@ -97,3 +97,18 @@ def test_c5_network_matches_the_reference_parameter_count():
     small = harness_c5.InpaintingNet(nb=1)
     y_hat, y_comp = small(torch.rand(1, 3, 16, 16), torch.ones(1, 1, 16, 16), torch.rand(1, 3, 2, 16, 16), torch.ones(1, 1, 2, 16, 16), torch.zeros(1, 1, 2, 16, 16))
     assert y_hat.shape == (1, 3, 2, 16, 16) and y_comp.shape == (1, 3, 2, 16, 16)
+
+
+def test_c3_network_matches_the_reference_layer_shapes():
+    """AlignmentNet restates ThesisAlignmentModel's trainable stacks.  The counts below are those of the reference's own
+    modules (SeparableConv4d, AlignmentCorrelationMixer, FlowEstimator of models/thesis_alignment.py, instantiated by
+    importing that file in the build container; parameter shapes and order were compared there and are identical)."""
+    from master_thesis_amd import harness_c3
+    net = harness_c3.AlignmentNet(harness_c3.FeatureStandIn())
+    n = lambda mod: sum(p.numel() for p in mod.parameters())
+    assert (n(net.conv4d), n(net.mixer), n(net.flow_64), n(net.flow_256)) == (1772801, 2278762, 4935682, 4935682)
+    assert sum(p.numel() for p in net.parameters() if p.requires_grad) == 13922927
+    vol = torch.rand(1, 2, 4, 4, 4, 4)
+    assert net.conv4d(vol).shape == vol.shape
+    flow = net.resize_flow_bilinear(torch.rand(1, 2, 4, 4, 2), 8, 8)
+    assert flow.shape == (1, 2, 8, 8, 2)
