@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from the raw PMC passes (r1_c2_hbm_bytes_raw.json, r1_ops_hbm_bytes_raw.json).
 
-The raw files are what `ab/pmc_bytes.sh` writes: per kernel, the average FETCH_SIZE and WRITE_SIZE (KiB) of two separate
+The raw files are what `profiles/microbench/pmc_bytes.sh` writes: per kernel, the average FETCH_SIZE and WRITE_SIZE (KiB) of two separate
 `rocprofv3 --pmc` passes over `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-variants` and
 `bench_ops.py --iters 2`.  hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE is doubled as
 MI355X_MICROARCH.md prescribes for gfx950 (a 128-byte request is counted as 64 bytes; calibrated there for 16-byte-per-lane
