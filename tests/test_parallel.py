@@ -112,3 +112,10 @@ def test_c3_network_matches_the_reference_layer_shapes():
     assert net.conv4d(vol).shape == vol.shape
     flow = net.resize_flow_bilinear(torch.rand(1, 2, 4, 4, 2), 8, 8)
     assert flow.shape == (1, 2, 8, 8, 2)
+
+
+def test_c4_network_matches_the_reference_parameter_count():
+    """CopyPasteNet restates CPNOriginal (models/cpn_original.py): 21,631,385 parameters in the reference, of which the
+    4,719,616 of A_Regressor.conv6a / conv6b are never used by its forward (it re-applies conv5a / conv5b, :103-104)."""
+    from master_thesis_amd import harness_c4
+    assert sum(p.numel() for p in harness_c4.CopyPasteNet().parameters()) == 21631385 - 4719616
