@@ -8,6 +8,8 @@ The sub-modules mirror the reference's module and function names for this path:
     master_thesis_amd.utils.flow          <- utils/flow.py
     master_thesis_amd.models.cpn          <- the hot-path parts of models/cpn.py
     master_thesis_amd.models.cpn_original <- CM_Module of models/cpn_original.py
+    master_thesis_amd.utils.movement      <- utils/movement.py (on the device)
+    master_thesis_amd.runners / schedulers <- the static step functions and sequence schedulers of the three runners
 
 `install_dropin()` registers them under the reference's own names (`utils.correlation`, `utils.flow`, and the
 hot-path symbols of `models.cpn` / `models.cpn_original`), see INTEGRATION.md.
@@ -48,4 +50,22 @@ def install_dropin(reference_modules=None):
         for sym in symbols:
             setattr(target, sym, getattr(src, sym))
             patched.append("%s.%s" % (name, sym))
+    # the sequence schedulers (static methods of the runner classes), if those modules are loaded: same signatures,
+    # and `schedulers.*_batched` is then available to callers that hold several sequences
+    from . import schedulers as _sched
+    runner_table = {
+        "thesis_inpainting.runner": ("ThesisInpaintingRunner", {
+            "inpainting_algorithm_ff": _sched.inpainting_algorithm_ff, "inpainting_algorithm_ip": _sched.inpainting_algorithm_ip,
+            "inpainting_algorithm_cp": _sched.inpainting_algorithm_cp, "inpainting_algorithm_ff_indexes": _sched.inpainting_algorithm_ff_indexes,
+            "inpainting_algorithm_ip_indexes": _sched.inpainting_algorithm_ip_indexes}),
+        "thesis_cpn.runner": ("ThesisCPNRunner", {
+            "inpainting_algorithm": _sched.inpainting_algorithm_cpn, "get_reference_frame_indexes": _sched.get_reference_frame_indexes}),
+    }
+    for name, (cls_name, methods) in runner_table.items():
+        cls = getattr(mods.get(name), cls_name, None) if mods.get(name) is not None else None
+        if cls is None:
+            continue
+        for meth, fn in methods.items():
+            setattr(cls, meth, staticmethod(fn))
+            patched.append("%s.%s.%s" % (name, cls_name, meth))
     return patched

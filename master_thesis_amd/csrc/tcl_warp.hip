@@ -86,8 +86,9 @@ template <bool W2>
 __device__ __forceinline__ TapVals fetch_taps(const float *plane, const Taps &t, int W) {
   TapVals v;
   if (W2) {
-    v.n = *reinterpret_cast<const F2U *>(plane + t.ya * W + t.xa);
-    v.s = *reinterpret_cast<const F2U *>(plane + t.yb * W + t.xa);
+    // unsigned 32-bit offsets off the (wave-uniform) plane pointer: one scalar base + vector offset per load, no 64-bit VALU
+    v.n = *reinterpret_cast<const F2U *>(plane + (unsigned)(t.ya * W + t.xa));
+    v.s = *reinterpret_cast<const F2U *>(plane + (unsigned)(t.yb * W + t.xa));
   } else {  // one-pixel-wide image
     v.n.a = plane[t.ya * W]; v.n.b = 0.f;
     v.s.a = plane[t.yb * W]; v.s.b = 0.f;

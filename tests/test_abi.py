@@ -82,3 +82,12 @@ def test_install_dropin_patches_reference_names():
     patched = m.install_dropin(fake)
     assert "utils.flow.align_set" in patched and "models.cpn_original.CM_Module" in patched
     assert fake["utils.correlation"].compute_masked_4d_correlation is m.utils.correlation.compute_masked_4d_correlation
+    # runner classes, when loaded, get the schedulers as static methods
+    fake["thesis_inpainting.runner"] = types.ModuleType("thesis_inpainting.runner")
+    fake["thesis_inpainting.runner"].ThesisInpaintingRunner = type("ThesisInpaintingRunner", (), {})
+    fake["thesis_cpn.runner"] = types.ModuleType("thesis_cpn.runner")
+    fake["thesis_cpn.runner"].ThesisCPNRunner = type("ThesisCPNRunner", (), {})
+    patched = m.install_dropin(fake)
+    assert "thesis_inpainting.runner.ThesisInpaintingRunner.inpainting_algorithm_cp" in patched
+    assert fake["thesis_inpainting.runner"].ThesisInpaintingRunner.inpainting_algorithm_ff_indexes(2, 5, 1, 20) == [1, 3, 0, 4]
+    assert fake["thesis_cpn.runner"].ThesisCPNRunner.get_reference_frame_indexes(0, 5) == [2]
