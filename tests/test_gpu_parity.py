@@ -522,3 +522,9 @@ def test_runner_step_functions_vs_oracle():
     assert_close(N(xa), oxa, what="infer x_aligned")
     assert_exact(N(va), ova, what="infer v_aligned")
     assert_exact(N(vm), O.v_map(ova, 1 - m[:, :, t]), what="infer v_map")
+
+
+def test_graft_entry_smoke_runs():
+    """The driver's smoke() (one small invocation of every hot-path op against the oracle) must keep working."""
+    import __graft_entry__ as entry
+    entry.smoke()
