@@ -277,31 +277,46 @@ static CtxWs ctx_ws(void *base, int64_t B, int64_t C, int64_t R, int64_t hw) {
   return w;
 }
 
-// both mask resizes of the forward pass in one launch: image n of B*(R+1) is v_t[b] (j == 0) or v_aligned[b][j-1]
+// Both mask resizes of the forward pass in one launch, one thread per (target, feature pixel): the target map and the R
+// reference maps share the bilinear taps, and the thread assembles the pixel's bit field(s) itself, so the bit fields
+// need neither a memset nor atomics.
+template <int RU>
 __global__ void __launch_bounds__(256) ctx_resize_masks_kernel(const float *__restrict__ v_t, const float *__restrict__ v_al,
                                                                float *__restrict__ vt, float *__restrict__ vr, unsigned *__restrict__ mbits,
-                                                               int B, int R, int H, int W, int h, int w, int passes, int ru) {
+                                                               int B, int R, int H, int W, int h, int w, int passes) {
   const float sh = __fdiv_rn((float)H, (float)h), sw = __fdiv_rn((float)W, (float)w);
   const int hw = h * w;
-  const int64_t total = (int64_t)B * (R + 1) * hw;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = i / hw;
-    const int r = (int)(i - n * hw), y = r / w, x = r - y * w;
-    const int b = (int)(n / (R + 1)), j = (int)(n - (int64_t)b * (R + 1));
-    const LinTap ty = linear_tap(y, H, sh), tx = linear_tap(x, W, sw);
-    const float *p = j == 0 ? v_t + (int64_t)b * H * W : v_al + ((int64_t)b * R + (j - 1)) * H * W;
-    const float val = bilerp(p[ty.i0 * W + tx.i0], p[ty.i0 * W + tx.i1], p[ty.i1 * W + tx.i0], p[ty.i1 * W + tx.i1], tx, ty);
-    float *o = j == 0 ? vt + (int64_t)b * hw : vr + ((int64_t)b * R + (j - 1)) * hw;
-    const bool on = val > 0.5f;
-    o[r] = on ? 1.f : 0.f;
-    if (on) {   // mbits was zeroed on the stream before this launch
-      if (j == 0) {
-        for (int q = 0; q < passes; ++q) atomicOr(mbits + ((int64_t)q * B + b) * hw + r, 1u);
-      } else {
-        const int q = (j - 1) / ru, k = (j - 1) - q * ru;
-        atomicOr(mbits + ((int64_t)q * B + b) * hw + r, 2u << k);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * hw) return;
+  const int b = i / hw, r = i - b * hw, y = r / w, x = r - y * w;
+  const LinTap ty = linear_tap(y, H, sh), tx = linear_tap(x, W, sw);
+  const int o00 = ty.i0 * W + tx.i0, o01 = ty.i0 * W + tx.i1, o10 = ty.i1 * W + tx.i0, o11 = ty.i1 * W + tx.i1;
+  const float *pt = v_t + (int64_t)b * H * W;
+  const float t00 = pt[o00], t01 = pt[o01], t10 = pt[o10], t11 = pt[o11];
+  bool t_on = false;
+  for (int q = 0; q < passes; ++q) {
+    float v[RU][4];
+#pragma unroll
+    for (int k = 0; k < RU; ++k) {   // the 4 * RU taps of the pass in flight together (clamped plane index, selected below)
+      const float *p = v_al + ((int64_t)b * R + min(q * RU + k, R - 1)) * H * W;
+      v[k][0] = p[o00]; v[k][1] = p[o01]; v[k][2] = p[o10]; v[k][3] = p[o11];
+    }
+    TCL_LOADS_FIRST(4 * RU);
+    if (q == 0) {
+      t_on = bilerp(t00, t01, t10, t11, tx, ty) > 0.5f;
+      vt[i] = t_on ? 1.f : 0.f;
+    }
+    unsigned bits = t_on ? 1u : 0u;
+#pragma unroll
+    for (int k = 0; k < RU; ++k) {
+      const int j = q * RU + k;
+      const bool on = bilerp(v[k][0], v[k][1], v[k][2], v[k][3], tx, ty) > 0.5f;
+      if (j < R) {
+        vr[((int64_t)b * R + j) * hw + r] = on ? 1.f : 0.f;
+        bits |= on ? 2u << k : 0u;
       }
     }
+    mbits[((int64_t)q * B + b) * hw + r] = bits;
   }
 }
 
@@ -372,39 +387,115 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 }
 
-// One wave per (b, r): gs from the C channel partials (v_sum, the `zeros` flag and the normalisation; flags bit-exact).
+// gs[b][r] from the C channel partials (v_sum, the `zeros` flag and the normalisation; flags bit-exact), by one wave.
+__device__ __forceinline__ void ctx_gs(const float *partial, const float *vsp, int br, int C, int variant, int normalize, int lane,
+                                       float &g_out, float &ds_out) {
+  float raw = 0.f;
+  for (int k = lane; k < C; k += 64) raw += partial[(int64_t)br * C + k];
+  raw = wave_sum(raw);
+  const float vs = vsp[br];
+  const bool zero = vs < 1e-4f;
+  const float v_sum = zero ? vs + 1.f : vs;
+  float g, ds;
+  if (variant == TCL_CTX_CM_MODULE) {        // gs / v_sum / C            (cpn_original.py:226)
+    g = (raw / v_sum) / (float)C;
+    ds = (1.f / v_sum) / (float)C;
+  } else if (normalize) {                    // gs / (v_sum * C)          (cpn.py:115-116)
+    g = raw / (v_sum * (float)C);
+    ds = 1.f / (v_sum * (float)C);
+  } else {
+    g = raw; ds = 1.f;
+  }
+  g_out = zero ? 0.f : g;
+  ds_out = zero ? 0.f : ds;
+}
+
+// One thread per (b, pixel): softmax over the references -> c_match (B,R,hw), c_mask and the mask channel of p_in.
+// The block first reduces the similarities of the (at most NBMAX) targets its 256 pixels belong to (what used to be a
+// separate finalize launch; every block that needs a target's gs computes the same value in the same order) and the block
+// that holds a target's first pixel stores gs / dscale for the backward pass.
+constexpr int CTX_WB = 4;   // targets a block of 256 pixels can straddle when hw >= 86
+template <int RU>   // RU = R when R <= CTX_RMAX (masks of the pixel loaded once, together), 0 = any R
+__global__ void __launch_bounds__(256) ctx_weights_kernel(const float *__restrict__ vt, const float *__restrict__ vr,
+                                                          const float *__restrict__ partial, const float *__restrict__ vsp,
+                                                          float *__restrict__ gs, float *__restrict__ dscale, float *__restrict__ p_in,
+                                                          float *__restrict__ c_mask, float *__restrict__ c_match, int B, int C, int R,
+                                                          int hw, int variant, int normalize) {
+  __shared__ float g_s[CTX_WB][64];
+  const int i0 = blockIdx.x * 256, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b_first = i0 / hw, b_last = min((i0 + 255) / hw, B - 1), nb = b_last - b_first + 1;   // nb <= CTX_WB (host checks hw)
+  for (int t = wv; t < nb * R; t += 4) {
+    const int bl = t / R, r = t - bl * R, br = (b_first + bl) * R + r;
+    float g, ds;
+    ctx_gs(partial, vsp, br, C, variant, normalize, lane, g, ds);
+    if (lane == 0) {
+      g_s[bl][r] = g;
+      if ((int64_t)(b_first + bl) * hw >= i0) { gs[br] = g; dscale[br] = ds; }   // this block holds the target's first pixel
+    }
+  }
+  __syncthreads();
+  const int i = i0 + threadIdx.x;
+  if (i >= B * hw) return;
+  const int b = i / hw, x = i - b * hw;
+  const float *vrb = vr + (int64_t)b * R * hw + x, *g = g_s[b - b_first];
+  const float vtx = vt[i];
+  const float hole = variant == TCL_CTX_COMPLETE ? 1.f - vtx : 1.f;
+  float cm = 0.f;
+  if (RU > 0) {
+    float m[RU > 0 ? RU : 1], e[RU > 0 ? RU : 1];
+#pragma unroll
+    for (int r = 0; r < RU; ++r) m[r] = vrb[(int64_t)r * hw];
+    TCL_LOADS_FIRST(RU);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < RU; ++r) mx = fmaxf(mx, g[r] * m[r]);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RU; ++r) { e[r] = expf(g[r] * m[r] - mx) * m[r]; s += e[r]; }
+    if (s < 1e-4f) s += 1.f;
+#pragma unroll
+    for (int r = 0; r < RU; ++r) {
+      const float wgt = (e[r] / s) * hole;
+      c_match[((int64_t)b * R + r) * hw + x] = wgt;
+      cm += wgt * m[r];
+    }
+  } else {
+    float mx = -INFINITY;
+    for (int r = 0; r < R; ++r) mx = fmaxf(mx, g[r] * vrb[(int64_t)r * hw]);
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const float m = vrb[(int64_t)r * hw];
+      s += expf(g[r] * m - mx) * m;
+    }
+    if (s < 1e-4f) s += 1.f;
+    for (int r = 0; r < R; ++r) {
+      const float m = vrb[(int64_t)r * hw];
+      const float wgt = (expf(g[r] * m - mx) * m / s) * hole;
+      c_match[((int64_t)b * R + r) * hw + x] = wgt;
+      cm += wgt * m;
+    }
+  }
+  cm = 1.f - cm;
+  c_mask[i] = cm;
+  const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
+  p_in[((int64_t)b * (cch + 1) + cch) * hw + x] = cm;
+}
+
+// Small feature maps (hw < 64: a block would straddle more than CTX_WB targets): the two-launch form.
 __global__ void __launch_bounds__(256) ctx_finalize_kernel(const float *__restrict__ partial, const float *__restrict__ vsp,
                                                            float *__restrict__ gs, float *__restrict__ dscale, int BR, int C,
                                                            int variant, int normalize) {
   const int br = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (br >= BR) return;
-  float raw = 0.f;
-  for (int k = lane; k < C; k += 64) raw += partial[(int64_t)br * C + k];
-  raw = wave_sum(raw);
-  if (lane == 0) {
-    const float vs = vsp[br];
-    const bool zero = vs < 1e-4f;
-    const float v_sum = zero ? vs + 1.f : vs;
-    float g, ds;
-    if (variant == TCL_CTX_CM_MODULE) {        // gs / v_sum / C            (cpn_original.py:226)
-      g = (raw / v_sum) / (float)C;
-      ds = (1.f / v_sum) / (float)C;
-    } else if (normalize) {                    // gs / (v_sum * C)          (cpn.py:115-116)
-      g = raw / (v_sum * (float)C);
-      ds = 1.f / (v_sum * (float)C);
-    } else {
-      g = raw; ds = 1.f;
-    }
-    gs[br] = zero ? 0.f : g;
-    dscale[br] = zero ? 0.f : ds;
-  }
+  float g, ds;
+  ctx_gs(partial, vsp, br, C, variant, normalize, lane, g, ds);
+  if (lane == 0) { gs[br] = g; dscale[br] = ds; }
 }
 
-// One thread per (b, pixel): softmax over the references -> c_match (B,R,hw), c_mask and the mask channel of p_in.
-__global__ void __launch_bounds__(256) ctx_weights_kernel(const float *__restrict__ vt, const float *__restrict__ vr,
-                                                          const float *__restrict__ gs, float *__restrict__ p_in,
-                                                          float *__restrict__ c_mask, float *__restrict__ c_match, int B, int C, int R,
-                                                          int hw, int variant) {
+__global__ void __launch_bounds__(256) ctx_weights_plain_kernel(const float *__restrict__ vt, const float *__restrict__ vr,
+                                                                const float *__restrict__ gs, float *__restrict__ p_in,
+                                                                float *__restrict__ c_mask, float *__restrict__ c_match, int B, int C, int R,
+                                                                int hw, int variant) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B * hw) return;
   const int b = i / hw, x = i - b * hw;
@@ -729,7 +820,7 @@ extern "C" int tcl_masked_softmax_bwd(const float *grad_out, const float *vec, c
 
 static int ctx_check(const char *fn, int64_t B, int64_t C, int64_t R, int64_t h, int64_t w, int variant) {
   TCL_REQUIRE(B > 0 && C > 0 && R > 0 && h > 0 && w > 0, TCL_ERR_SHAPE, "%s: bad shape B=%ld C=%ld R=%ld h=%ld w=%ld", fn, (long)B, (long)C, (long)R, (long)h, (long)w);
-  TCL_REQUIRE(B < 65536 && h * w < (1 << 24) && C * h * w < (1LL << 31) && R <= 64 && B * C < (1LL << 31), TCL_ERR_SHAPE, "%s: shape out of range (R <= 64, B < 65536)", fn);
+  TCL_REQUIRE(B < 65536 && h * w < (1 << 24) && C * h * w < (1LL << 31) && R <= 64 && B * C < (1LL << 31) && B * h * w < (1LL << 31), TCL_ERR_SHAPE, "%s: shape out of range (R <= 64, B < 65536)", fn);
   TCL_REQUIRE(variant >= TCL_CTX_DEFAULT && variant <= TCL_CTX_CM_MODULE, TCL_ERR_ARG, "%s: unknown variant %d", fn, variant);
   return TCL_OK;
 }
@@ -752,10 +843,7 @@ extern "C" int tcl_ctx_fwd(const float *c_feats, const float *v_t, const float *
   hipStream_t s = (hipStream_t)stream;
   const int hw = (int)(h * w);
   const CtxWs ws = ctx_ws(workspace, B, C, R, hw);
-  if (hipMemsetAsync(ws.mbits, 0, (size_t)ws.passes * B * hw * sizeof(unsigned), s) != hipSuccess)
-    return set_error(TCL_ERR_LAUNCH, "tcl_ctx_fwd: hipMemsetAsync failed");
-  hipLaunchKernelGGL(ctx_resize_masks_kernel, dim3(stream_blocks(B * (R + 1) * hw)), dim3(256), 0, s, v_t, v_aligned, ws.vt, ws.vr, ws.mbits,
-                     (int)B, (int)R, (int)H, (int)W, (int)h, (int)w, ws.passes, ws.ru);
+
   const int px = ctx_px(hw);
   const int BC = (int)(B * C);
   const dim3 grd((unsigned)cdiv(BC, 4)), blk(256);
@@ -776,11 +864,21 @@ extern "C" int tcl_ctx_fwd(const float *c_feats, const float *v_t, const float *
       case 30: WHAT(15, 1); break; case 31: WHAT(15, 2); break; case 32: WHAT(16, 1); break; default: WHAT(16, 2); break;  \
     }                                                                                       \
   } while (0)
+#define TCL_CTX_RSZ(RU, PX) hipLaunchKernelGGL((ctx_resize_masks_kernel<RU>), dim3((unsigned)cdiv(B * hw, 256)), blk, 0, s, v_t, v_aligned, ws.vt, ws.vr, ws.mbits, (int)B, (int)R, (int)H, (int)W, (int)h, (int)w, ws.passes)
+  TCL_CTX_BY_R(TCL_CTX_RSZ);
+#undef TCL_CTX_RSZ
   for (r0 = 0; r0 < R; r0 += ru) TCL_CTX_BY_R(TCL_CTX_SIM);
-  hipLaunchKernelGGL(ctx_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, ws.partial, ws.vsp, ws.gs, ws.dscale, (int)(B * R),
-                     (int)C, variant, normalize);
-  hipLaunchKernelGGL(ctx_weights_kernel, dim3((unsigned)cdiv(B * hw, 256)), dim3(256), 0, s, ws.vt, ws.vr, ws.gs, p_in, c_mask, c_match,
-                     (int)B, (int)C, (int)R, hw, variant);
+  if (hw >= 86) {   // 256 consecutive pixels touch at most ceil(255 / hw) + 1 <= CTX_WB targets
+#define TCL_CTX_WGT(RU, PX) hipLaunchKernelGGL((ctx_weights_kernel<RU>), dim3((unsigned)cdiv(B * hw, 256)), blk, 0, s, ws.vt, ws.vr, ws.partial, ws.vsp, ws.gs, ws.dscale, p_in, c_mask, c_match, (int)B, (int)C, (int)R, hw, variant, normalize)
+    if (ws.passes == 1) TCL_CTX_BY_R(TCL_CTX_WGT);   // ru == R
+    else TCL_CTX_WGT(0, 1);
+#undef TCL_CTX_WGT
+  } else {
+    hipLaunchKernelGGL(ctx_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, ws.partial, ws.vsp, ws.gs, ws.dscale, (int)(B * R),
+                       (int)C, variant, normalize);
+    hipLaunchKernelGGL(ctx_weights_plain_kernel, dim3((unsigned)cdiv(B * hw, 256)), dim3(256), 0, s, ws.vt, ws.vr, ws.gs, p_in, c_mask, c_match,
+                       (int)B, (int)C, (int)R, hw, variant);
+  }
   for (r0 = 0; r0 < R; r0 += ru) TCL_CTX_BY_R(TCL_CTX_AGG);
 #undef TCL_CTX_SIM
 #undef TCL_CTX_AGG
