@@ -690,6 +690,61 @@ __global__ void __launch_bounds__(256) ctx_bwd_jacobian_kernel(const float *__re
   }
 }
 
+// R <= 16: one wave per block over 64 pixels, the R masks, exponentials and d_match sums stay in registers (all loads issued
+// before the first use), no LDS and no barrier; 4x the blocks of the generic kernel, which at C4's 60 x 106 map is 400 instead of 100.
+template <int RU>
+__global__ void __launch_bounds__(64) ctx_bwd_jacobian_small_kernel(const float *__restrict__ g_p_in, const float *__restrict__ g_c_mask,
+                                                                    const float *__restrict__ dpart, const float *__restrict__ vt,
+                                                                    const float *__restrict__ vr, const float *__restrict__ gs,
+                                                                    float *__restrict__ partial, int B, int C, int hw, int variant,
+                                                                    int csplit, int nbx) {
+  const int b = blockIdx.y, lane = threadIdx.x;
+  const int x0 = blockIdx.x * 64 + lane;
+  const bool ok = x0 < hw;
+  const int x = ok ? x0 : 0;
+  const int cch = variant == TCL_CTX_COMPLETE ? C : 2 * C;
+  const float *vrb = vr + (int64_t)b * RU * hw + x;
+  const float *g = gs + (int64_t)b * RU;
+  float m[RU], d[RU], e[RU];
+#pragma unroll
+  for (int r = 0; r < RU; ++r) m[r] = vrb[(int64_t)r * hw];
+#pragma unroll
+  for (int r = 0; r < RU; ++r) d[r] = dpart[((int64_t)b * RU + r) * hw + x];
+  float gmask = g_p_in[((int64_t)b * (cch + 1) + cch) * hw + x];
+  if (g_c_mask) gmask += g_c_mask[(int64_t)b * hw + x];
+  const float hole = variant == TCL_CTX_COMPLETE ? 1.f - vt[(int64_t)b * hw + x] : 1.f;
+  for (int q = 1; q < csplit; ++q) {
+#pragma unroll
+    for (int r = 0; r < RU; ++r) d[r] += dpart[(((int64_t)q * B + b) * RU + r) * hw + x];
+  }
+  float mx = -INFINITY, s = 0.f, ge = 0.f, tot = 0.f;
+  int am = 0;
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    e[r] = g[r] * m[r];
+    if (e[r] > mx) { mx = e[r]; am = r; }
+  }
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    e[r] = expf(e[r] - mx) * m[r];
+    d[r] = (d[r] - gmask * m[r]) * hole;   // d loss / d softmax_r
+    s += e[r];
+    ge += d[r] * e[r];
+  }
+  const float sp = s < 1e-4f ? s + 1.f : s;
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    d[r] = (d[r] / sp - ge / (sp * sp)) * e[r];
+    tot += d[r];
+  }
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    float o = r == am ? d[r] - tot : d[r];
+    o = wave_sum(ok ? o * m[r] : 0.f);
+    if (lane == 0) partial[((int64_t)b * RU + r) * nbx + blockIdx.x] = o;
+  }
+}
+
 // coef[b,r] = dscale[b,r] * sum_blocks partial   (one wave per (b,r))
 __global__ void __launch_bounds__(256) ctx_bwd_finalize_kernel(const float *__restrict__ partial, const float *__restrict__ dscale,
                                                                float *__restrict__ coef, int BR, int nbx) {
@@ -896,7 +951,7 @@ static int ctx_bwd_ru(int64_t R) { return (int)cdiv(R, cdiv(R, CTX_RC)); }   // 
 
 extern "C" size_t tcl_ctx_bwd_workspace_bytes(int64_t B, int64_t C, int64_t R, int64_t h, int64_t w) {
   if (B <= 0 || C <= 0 || R <= 0 || h <= 0 || w <= 0) return 0;
-  return round_up((size_t)B * R * cdiv(h * w, 256) * 4, 256) + round_up((size_t)B * R * 4, 256) +
+  return round_up((size_t)B * R * cdiv(h * w, 64) * 4, 256) + round_up((size_t)B * R * 4, 256) +
          round_up((size_t)ctx_bwd_csplit(B, C, h * w) * B * R * h * w * 4, 256);
 }
 
@@ -912,10 +967,11 @@ extern "C" int tcl_ctx_bwd(const float *g_p_in, const float *g_c_mask, const flo
   TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
               "tcl_ctx_bwd: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
   hipStream_t s = (hipStream_t)stream;
-  const int hw = (int)(h * w), nbx = (int)cdiv(hw, 256);
+  const bool small = R <= 16;   // one wave per 64 pixels (registers only), else 256 pixels per block through LDS
+  const int hw = (int)(h * w), nbx = (int)cdiv(hw, small ? 64 : 256);
   const CtxWs ws = ctx_ws(const_cast<void *>(fwd_workspace), B, C, R, hw);
   float *partial = (float *)workspace;
-  float *coef = (float *)((char *)workspace + round_up((size_t)B * R * nbx * 4, 256));
+  float *coef = (float *)((char *)workspace + round_up((size_t)B * R * cdiv(hw, 64) * 4, 256));
   float *dpart = (float *)((char *)coef + round_up((size_t)B * R * 4, 256));
   const int csplit = ctx_bwd_csplit(B, C, hw), xb = ctx_xblocks(hw), px = ctx_px(hw), ru = ctx_bwd_ru(R);
   const dim3 grd((unsigned)(xb * csplit), (unsigned)B), blk(256);
@@ -937,8 +993,15 @@ extern "C" int tcl_ctx_bwd(const float *g_p_in, const float *g_c_mask, const flo
   }
 #undef TCL_CTX_DM_PX
 #undef TCL_CTX_DM
-  hipLaunchKernelGGL(ctx_bwd_jacobian_kernel, dim3((unsigned)nbx, (unsigned)B), dim3(256), (size_t)R * 256 * sizeof(float), s, g_p_in, g_c_mask,
-                     dpart, ws.vt, ws.vr, ws.gs, partial, (int)B, (int)C, (int)R, hw, variant, csplit, nbx);
+#define TCL_CTX_JAC(RU) case RU: hipLaunchKernelGGL(ctx_bwd_jacobian_small_kernel<RU>, dim3((unsigned)nbx, (unsigned)B), dim3(64), 0, s, g_p_in, g_c_mask, dpart, ws.vt, ws.vr, ws.gs, partial, (int)B, (int)C, hw, variant, csplit, nbx); break
+  switch (small ? (int)R : 0) {
+    TCL_CTX_JAC(1); TCL_CTX_JAC(2); TCL_CTX_JAC(3); TCL_CTX_JAC(4); TCL_CTX_JAC(5); TCL_CTX_JAC(6); TCL_CTX_JAC(7); TCL_CTX_JAC(8);
+    TCL_CTX_JAC(9); TCL_CTX_JAC(10); TCL_CTX_JAC(11); TCL_CTX_JAC(12); TCL_CTX_JAC(13); TCL_CTX_JAC(14); TCL_CTX_JAC(15); TCL_CTX_JAC(16);
+    default:
+      hipLaunchKernelGGL(ctx_bwd_jacobian_kernel, dim3((unsigned)nbx, (unsigned)B), dim3(256), (size_t)R * 256 * sizeof(float), s, g_p_in, g_c_mask,
+                         dpart, ws.vt, ws.vr, ws.gs, partial, (int)B, (int)C, (int)R, hw, variant, csplit, nbx);
+  }
+#undef TCL_CTX_JAC
   hipLaunchKernelGGL(ctx_bwd_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, partial, ws.dscale, coef, (int)(B * R), nbx);
   if (ctx_px(hw) == 2)
     hipLaunchKernelGGL(ctx_bwd_feats_kernel<2>, dim3((unsigned)(ctx_xblocks(hw) * cdiv(C, 4) * B)), dim3(64, 4), 0, s, g_p_in, c_feats,
