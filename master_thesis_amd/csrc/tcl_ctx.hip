@@ -246,10 +246,11 @@ struct CtxWs {
   float *vr;       // (B,R,hw) resized reference visibility
   float *gs;       // (B,R)    similarity after normalisation / zeroing
   float *dscale;   // (B,R)    d gs / d raw sum  (0 where v_sum was zero)
-  float *partial;  // (B,R,C) per-channel partial sums of the raw similarity
-  float *vsp;      // (B,R)   overlap area  sum_x vt*vr
+  float *partial;  // (B,R,C,xs) per-channel, per-pixel-range partial sums of the raw similarity
+  float *vsp;      // (B,R,xs)  overlap area  sum_x vt*vr, per pixel range
   unsigned *mbits; // (passes,B,hw) per pixel: bit 0 = vt, bit 1+k = vr of reference pass*ru + k (the similarity kernel's masks in one load)
   int passes, ru;  // references are handled in `passes` launches of `ru` <= CTX_RMAX each
+  int xs;          // pixel ranges the similarity kernel splits a channel slab into (enough waves to fill the chip at small B*C)
   size_t bytes;
 };
 constexpr int CTX_PXW = 64;  // lanes along the pixel axis; each lane owns PX (1 or 2) adjacent pixels
@@ -260,6 +261,18 @@ constexpr int CTX_RMAX = 16;  // references per launch of the slab kernels (one 
 
 static int ctx_xblocks(int64_t hw) { return (int)cdiv(hw, CTX_PXW * ctx_px(hw)); }
 
+// Slab kernels run one wave per (target, channel [pair]); at C4 (B = 4, C = 128) that is 256 / 512 waves on 256 CUs, far too
+// few loads in flight for HBM.  The pixel axis is therefore cut into `xs` ranges (grid.y) until about `want` waves exist, each
+// range keeping at least 4 steps of 64 * PX pixels.  A function of the shape only: the summation order stays deterministic.
+static int ctx_xsplit(int64_t waves, int64_t hw, int64_t want) {
+  static const int forced = [] { const char *e = getenv("TCL_CTX_XS"); return e ? atoi(e) : 0; }();
+  const int64_t nst = cdiv(hw, CTX_PXW * ctx_px(hw));
+  int64_t xs = forced > 0 ? forced : cdiv(want, waves);
+  if (xs > nst / 4) xs = nst / 4;
+  if (xs > 16) xs = 16;
+  return (int)(xs < 1 ? 1 : xs);
+}
+
 static CtxWs ctx_ws(void *base, int64_t B, int64_t C, int64_t R, int64_t hw) {
   CtxWs w;
   size_t off = 0;
@@ -268,8 +281,9 @@ static CtxWs ctx_ws(void *base, int64_t B, int64_t C, int64_t R, int64_t hw) {
   w.vr = take((size_t)B * R * hw);
   w.gs = take((size_t)B * R);
   w.dscale = take((size_t)B * R);
-  w.partial = take((size_t)B * R * C);
-  w.vsp = take((size_t)B * R);
+  w.xs = ctx_xsplit(B * ((C + 1) / 2), hw, 2048);
+  w.partial = take((size_t)B * R * C * w.xs);
+  w.vsp = take((size_t)B * R * w.xs);
   w.passes = (int)cdiv(R, CTX_RMAX);
   w.ru = (int)cdiv(R, w.passes);
   w.mbits = (unsigned *)take((size_t)w.passes * B * hw);
@@ -343,8 +357,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   int rr[RU];   // references r0 .. r0+RU-1 of this pass (clamped: the padding ones are loaded but never written)
 #pragma unroll
   for (int k = 0; k < RU; ++k) { acc1[k] = acc2[k] = vs[k] = 0.f; rr[k] = min(r0 + k, R - 1); }
-  for (int x0 = lane * PX; x0 < hw + (CTX_PXW - 1) * PX; x0 += CTX_PXW * PX) {   // every lane takes the same number of steps
-    const bool ok = x0 < hw;
+  const int xs = gridDim.y, xj = blockIdx.y, per = (hw + CTX_PXW * PX * xs - 1) / (CTX_PXW * PX * xs) * (CTX_PXW * PX);
+  const int xbeg = xj * per, xend = min(hw, xbeg + per);   // this block's pixel range (whole steps; may be empty: zeros are written)
+  for (int x0 = xbeg + lane * PX; x0 < xend + (CTX_PXW - 1) * PX; x0 += CTX_PXW * PX) {   // every lane takes the same number of steps
+    const bool ok = x0 < xend;
     const int x = ok ? x0 : 0;
     float t1[PX], t2[PX], f1[RU][PX], f2[RU][PX];
     unsigned bits[PX];
@@ -374,26 +390,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   for (int k = 0; k < RU; ++k) {
     const float a = wave_sum(acc1[k]), a2 = wave_sum(acc2[k]);
     if (lane == 0 && r0 + k < R) {
-      partial[((int64_t)b * R + r0 + k) * C + c] = a;
-      if (has2) partial[((int64_t)b * R + r0 + k) * C + c + 1] = a2;
+      partial[(((int64_t)b * R + r0 + k) * C + c) * xs + xj] = a;
+      if (has2) partial[(((int64_t)b * R + r0 + k) * C + c + 1) * xs + xj] = a2;
     }
   }
   if (c == 0) {   // wave-uniform: the overlap area, a count of {0,1} products (exact)
 #pragma unroll
     for (int k = 0; k < RU; ++k) {
       const float v = wave_sum(vs[k]);
-      if (lane == 0 && r0 + k < R) vsp[b * R + r0 + k] = v;
+      if (lane == 0 && r0 + k < R) vsp[(b * R + r0 + k) * xs + xj] = v;
     }
   }
 }
 
 // gs[b][r] from the C channel partials (v_sum, the `zeros` flag and the normalisation; flags bit-exact), by one wave.
-__device__ __forceinline__ void ctx_gs(const float *partial, const float *vsp, int br, int C, int variant, int normalize, int lane,
+__device__ __forceinline__ void ctx_gs(const float *partial, const float *vsp, int br, int C, int xs, int variant, int normalize, int lane,
                                        float &g_out, float &ds_out) {
-  float raw = 0.f;
-  for (int k = lane; k < C; k += 64) raw += partial[(int64_t)br * C + k];
+  float raw = 0.f, vs = 0.f;
+  const int n = C * xs;
+  for (int k = lane; k < n; k += 64) raw += partial[(int64_t)br * n + k];
   raw = wave_sum(raw);
-  const float vs = vsp[br];
+  for (int j = 0; j < xs; ++j) vs += vsp[br * xs + j];   // counts: exact in any order
   const bool zero = vs < 1e-4f;
   const float v_sum = zero ? vs + 1.f : vs;
   float g, ds;
@@ -420,14 +437,14 @@ __global__ void __launch_bounds__(256) ctx_weights_kernel(const float *__restric
                                                           const float *__restrict__ partial, const float *__restrict__ vsp,
                                                           float *__restrict__ gs, float *__restrict__ dscale, float *__restrict__ p_in,
                                                           float *__restrict__ c_mask, float *__restrict__ c_match, int B, int C, int R,
-                                                          int hw, int variant, int normalize) {
+                                                          int hw, int variant, int normalize, int xs) {
   __shared__ float g_s[CTX_WB][64];
   const int i0 = blockIdx.x * 256, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b_first = i0 / hw, b_last = min((i0 + 255) / hw, B - 1), nb = b_last - b_first + 1;   // nb <= CTX_WB (host checks hw)
   for (int t = wv; t < nb * R; t += 4) {
     const int bl = t / R, r = t - bl * R, br = (b_first + bl) * R + r;
     float g, ds;
-    ctx_gs(partial, vsp, br, C, variant, normalize, lane, g, ds);
+    ctx_gs(partial, vsp, br, C, xs, variant, normalize, lane, g, ds);
     if (lane == 0) {
       g_s[bl][r] = g;
       if ((int64_t)(b_first + bl) * hw >= i0) { gs[br] = g; dscale[br] = ds; }   // this block holds the target's first pixel
@@ -484,11 +501,11 @@ __global__ void __launch_bounds__(256) ctx_weights_kernel(const float *__restric
 // Small feature maps (hw < 64: a block would straddle more than CTX_WB targets): the two-launch form.
 __global__ void __launch_bounds__(256) ctx_finalize_kernel(const float *__restrict__ partial, const float *__restrict__ vsp,
                                                            float *__restrict__ gs, float *__restrict__ dscale, int BR, int C,
-                                                           int variant, int normalize) {
+                                                           int variant, int normalize, int xs) {
   const int br = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (br >= BR) return;
   float g, ds;
-  ctx_gs(partial, vsp, br, C, variant, normalize, lane, g, ds);
+  ctx_gs(partial, vsp, br, C, xs, variant, normalize, lane, g, ds);
   if (lane == 0) { gs[br] = g; dscale[br] = ds; }
 }
 
@@ -541,7 +558,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
   float live[RU];
 #pragma unroll
   for (int k = 0; k < RU; ++k) { rr[k] = min(r0 + k, R - 1); live[k] = r0 + k < R ? 1.f : 0.f; }
-  for (int x = lane * PX; x < hw; x += CTX_PXW * PX) {
+  const int xs = gridDim.y, per = (hw + CTX_PXW * PX * xs - 1) / (CTX_PXW * PX * xs) * (CTX_PXW * PX);
+  const int xbeg = blockIdx.y * per, xend = min(hw, xbeg + per);   // this block's pixel range, see ctx_xsplit
+  for (int x = xbeg + lane * PX; x < xend; x += CTX_PXW * PX) {
     float ft[PX], vtx[PX], fr[RU][PX], w[RU][PX], acc[PX];
     ldpx<PX>(slab + x, ft);
     ldpx<PX>(vtb + x, vtx);
@@ -798,6 +817,68 @@ __global__ void __launch_bounds__(256) ctx_bwd_feats_kernel(const float *__restr
   stpx<PX>(g_cf + base, g_ft);
 }
 
+// R <= 16: the same pass with the reference count as a template parameter: every load of the thread (3 per reference and
+// channel-independent ones shared by its CH channels) is issued before the first use, then the R+1 stores follow.
+template <int RU, int PX, int CH>
+__global__ void __launch_bounds__(256) ctx_bwd_feats_small_kernel(const float *__restrict__ g_p_in, const float *__restrict__ cf,
+                                                                  const float *__restrict__ c_match, const float *__restrict__ vt,
+                                                                  const float *__restrict__ vr, const float *__restrict__ coef,
+                                                                  float *__restrict__ g_cf, int C, int hw, int variant, unsigned xblocks) {
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x), cgroups = (C + 4 * CH - 1) / (4 * CH);
+  const unsigned bxi = lin % xblocks, rest = lin / xblocks;
+  const int b = rest / cgroups, c0 = ((rest % cgroups) * 4 + threadIdx.y) * CH;
+  const int x = (bxi * CTX_PXW + threadIdx.x) * PX;
+  if (x >= hw || c0 >= C) return;
+  const bool complete = variant == TCL_CTX_COMPLETE;
+  const int cch = complete ? C : 2 * C;
+  const float *gpb = g_p_in + (int64_t)b * (cch + 1) * hw + x;
+  float vtx[PX], g_ft[CH][PX], g_out[CH][PX], ft[CH][PX], m[RU][PX], cm[RU][PX], fr[CH][RU][PX];
+  int64_t base[CH];
+  ldpx<PX>(vt + (int64_t)b * hw + x, vtx);
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int c = min(c0 + j, C - 1);   // a padding channel repeats the last one and is not stored
+    base[j] = ((int64_t)b * C + c) * (RU + 1) * hw + x;
+    ldpx<PX>(gpb + (int64_t)c * hw, g_ft[j]);
+    ldpx<PX>(gpb + (int64_t)(complete ? c : C + c) * hw, g_out[j]);
+    ldpx<PX>(cf + base[j], ft[j]);
+  }
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    ldpx<PX>(vr + ((int64_t)b * RU + r) * hw + x, m[r]);
+    ldpx<PX>(c_match + ((int64_t)b * RU + r) * hw + x, cm[r]);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) ldpx<PX>(cf + base[j] + (int64_t)(r + 1) * hw, fr[j][r]);
+  }
+  TCL_LOADS_FIRST(1 + 3 * CH + (2 + CH) * RU);
+  if (complete) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+      for (int e = 0; e < PX; ++e) g_ft[j][e] = g_out[j][e] * vtx[e];
+  }
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    const float cr = coef[b * RU + r];
+    float k[PX];
+#pragma unroll
+    for (int e = 0; e < PX; ++e) k[e] = cr * (vtx[e] * m[r][e]);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float o[PX];
+#pragma unroll
+      for (int e = 0; e < PX; ++e) {
+        g_ft[j][e] += k[e] * fr[j][r][e];
+        o[e] = g_out[j][e] * cm[r][e] + k[e] * ft[j][e];
+      }
+      if (c0 + j < C) stpx<PX>(g_cf + base[j] + (int64_t)(r + 1) * hw, o);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j)
+    if (c0 + j < C) stpx<PX>(g_cf + base[j], g_ft[j]);
+}
+
 static unsigned stream_blocks(int64_t total) {
   int64_t blocks = cdiv(total, 256);
   if (blocks > kMaxStreamBlocks * 2) blocks = kMaxStreamBlocks * 2;
@@ -901,10 +982,10 @@ extern "C" int tcl_ctx_fwd(const float *c_feats, const float *v_t, const float *
 
   const int px = ctx_px(hw);
   const int BC = (int)(B * C);
-  const dim3 grd((unsigned)cdiv(BC, 4)), blk(256);
+  const dim3 grd((unsigned)cdiv(BC, 4), (unsigned)ctx_xsplit(BC, hw, 4096)), blk(256);
   const int ru = ws.ru;
   int r0 = 0;
-#define TCL_CTX_SIM(RU, PX) hipLaunchKernelGGL((ctx_sim_kernel<RU, PX>), dim3((unsigned)cdiv(B * ((C + 1) / 2), 4)), blk, 0, s, c_feats, ws.mbits, ws.partial, ws.vsp, (int)B, (int)C, hw, (int)R, r0)
+#define TCL_CTX_SIM(RU, PX) hipLaunchKernelGGL((ctx_sim_kernel<RU, PX>), dim3((unsigned)cdiv(B * ((C + 1) / 2), 4), (unsigned)ws.xs), blk, 0, s, c_feats, ws.mbits, ws.partial, ws.vsp, (int)B, (int)C, hw, (int)R, r0)
 #define TCL_CTX_AGG(RU, PX) hipLaunchKernelGGL((ctx_aggregate_kernel<RU, PX>), grd, blk, 0, s, c_feats, ws.vt, c_match, p_in, BC, (int)C, hw, variant, (int)R, r0)
 #define TCL_CTX_BY_R(WHAT)                                                                  \
   do {                                                                                      \
@@ -924,13 +1005,13 @@ extern "C" int tcl_ctx_fwd(const float *c_feats, const float *v_t, const float *
 #undef TCL_CTX_RSZ
   for (r0 = 0; r0 < R; r0 += ru) TCL_CTX_BY_R(TCL_CTX_SIM);
   if (hw >= 86) {   // 256 consecutive pixels touch at most ceil(255 / hw) + 1 <= CTX_WB targets
-#define TCL_CTX_WGT(RU, PX) hipLaunchKernelGGL((ctx_weights_kernel<RU>), dim3((unsigned)cdiv(B * hw, 256)), blk, 0, s, ws.vt, ws.vr, ws.partial, ws.vsp, ws.gs, ws.dscale, p_in, c_mask, c_match, (int)B, (int)C, (int)R, hw, variant, normalize)
+#define TCL_CTX_WGT(RU, PX) hipLaunchKernelGGL((ctx_weights_kernel<RU>), dim3((unsigned)cdiv(B * hw, 256)), blk, 0, s, ws.vt, ws.vr, ws.partial, ws.vsp, ws.gs, ws.dscale, p_in, c_mask, c_match, (int)B, (int)C, (int)R, hw, variant, normalize, ws.xs)
     if (ws.passes == 1) TCL_CTX_BY_R(TCL_CTX_WGT);   // ru == R
     else TCL_CTX_WGT(0, 1);
 #undef TCL_CTX_WGT
   } else {
     hipLaunchKernelGGL(ctx_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, ws.partial, ws.vsp, ws.gs, ws.dscale, (int)(B * R),
-                       (int)C, variant, normalize);
+                       (int)C, variant, normalize, ws.xs);
     hipLaunchKernelGGL(ctx_weights_plain_kernel, dim3((unsigned)cdiv(B * hw, 256)), dim3(256), 0, s, ws.vt, ws.vr, ws.gs, p_in, c_mask, c_match,
                        (int)B, (int)C, (int)R, hw, variant);
   }
@@ -1003,11 +1084,21 @@ extern "C" int tcl_ctx_bwd(const float *g_p_in, const float *g_c_mask, const flo
   }
 #undef TCL_CTX_JAC
   hipLaunchKernelGGL(ctx_bwd_finalize_kernel, dim3((unsigned)cdiv(B * R, 4)), dim3(256), 0, s, partial, ws.dscale, coef, (int)(B * R), nbx);
+  // two channels per thread: the masks and match weights of a pixel are loaded once for both (0.216 -> 0.200 ms at C4 over one)
+#define TCL_CTX_FE3(RU, PX, CH) hipLaunchKernelGGL((ctx_bwd_feats_small_kernel<RU, PX, CH>), dim3((unsigned)(ctx_xblocks(hw) * cdiv(C, 4 * CH) * B)), dim3(64, 4), 0, s, g_p_in, c_feats, c_match, ws.vt, ws.vr, coef, g_c_feats, (int)C, hw, variant, (unsigned)ctx_xblocks(hw))
+#define TCL_CTX_FE(RU) case RU: if (px == 2) TCL_CTX_FE3(RU, 2, 2); else TCL_CTX_FE3(RU, 1, 2); break
+  switch (small ? (int)R : 0) {
+    TCL_CTX_FE(1); TCL_CTX_FE(2); TCL_CTX_FE(3); TCL_CTX_FE(4); TCL_CTX_FE(5); TCL_CTX_FE(6); TCL_CTX_FE(7); TCL_CTX_FE(8);
+    TCL_CTX_FE(9); TCL_CTX_FE(10); TCL_CTX_FE(11); TCL_CTX_FE(12); TCL_CTX_FE(13); TCL_CTX_FE(14); TCL_CTX_FE(15); TCL_CTX_FE(16);
+    default:
   if (ctx_px(hw) == 2)
     hipLaunchKernelGGL(ctx_bwd_feats_kernel<2>, dim3((unsigned)(ctx_xblocks(hw) * cdiv(C, 4) * B)), dim3(64, 4), 0, s, g_p_in, c_feats,
                        c_match, ws.vt, ws.vr, coef, g_c_feats, (int)C, (int)R, hw, variant, (unsigned)ctx_xblocks(hw));
   else
     hipLaunchKernelGGL(ctx_bwd_feats_kernel<1>, dim3((unsigned)(ctx_xblocks(hw) * cdiv(C, 4) * B)), dim3(64, 4), 0, s, g_p_in, c_feats,
                        c_match, ws.vt, ws.vr, coef, g_c_feats, (int)C, (int)R, hw, variant, (unsigned)ctx_xblocks(hw));
+  }
+#undef TCL_CTX_FE
+#undef TCL_CTX_FE3
   return check_launch("tcl_ctx_bwd");
 }

@@ -388,6 +388,9 @@ def test_warp_generic_channel_counts(C, F, H, W):
     (2, 5, 33, 4, 6, "cm_module"),    # three passes
     (1, 1, 1, 3, 3, "default"),       # the smallest of everything
     (1, 130, 9, 9, 14, "default"),    # more channels than one d_match block covers
+    (1, 8, 4, 40, 53, "default"),     # few waves, large map: the slab kernels split the pixel axis into 4 ranges (ragged last one)
+    (1, 6, 18, 33, 41, "complete"),   # pixel ranges + two reference passes + one pixel per lane
+    (1, 2, 2, 65, 128, "cm_module"),  # 16 pixel ranges of 5 steps over 65 steps: the last two ranges are empty
 ])
 def test_context_matching_shape_corners(mods, B, C, R, h, w, variant):
     rng = np.random.default_rng(R * 10 + C)
