@@ -30,7 +30,7 @@ ROWS = [  # (label, raw file, kernel-name substring, algorithmic bytes per launc
     ("ctx_sim (C4, 32 targets)", "ops", "ctx_sim_kernel", CF),
     ("ctx_aggregate (C4)", "ops", "ctx_aggregate_kernel", CF + 32 * 257 * 30 * 53 * 4),
     ("ctx_bwd_dmatch (C4)", "ops", "ctx_bwd_dmatch_kernel", CF),
-    ("ctx_bwd_feats (C4)", "ops", "ctx_bwd_feats_kernel", 2 * CF + 32 * 257 * 30 * 53 * 4),
+    ("ctx_bwd_feats (C4)", "ops", "ctx_bwd_feats_", 2 * CF + 32 * 257 * 30 * 53 * 4),
     ("ref_importance (C4)", "ops", "ref_importance_kernel", 32 * 3 * 11 * 240 * 424 * 4),
     ("masked_softmax fwd (C4 shape)", "ops", "masked_softmax_fwd_small_kernel", 32 * 128 * 10 * 30 * 53 * 8),
     ("corr1x1 fwd (32,256,64,64)", "ops", "corr1x1_fwd_kernel", 2 * 32 * 256 * 4096 * 4),
