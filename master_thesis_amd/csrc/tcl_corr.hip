@@ -32,11 +32,13 @@ template <int PX> struct PxV { float v[PX]; };
 template <int PX> __device__ __forceinline__ PxV<PX> ldv(const float *p) {
   PxV<PX> r;
   if (PX == 4) { const f32x4 t = *reinterpret_cast<const f32x4 *>(p); r.v[0] = t[0]; r.v[1 % PX] = t[1]; r.v[2 % PX] = t[2]; r.v[3 % PX] = t[3]; }
+  else if (PX == 2) { const tcl_f2 t = *reinterpret_cast<const tcl_f2 *>(p); r.v[0] = t[0]; r.v[1 % PX] = t[1]; }
   else r.v[0] = p[0];
   return r;
 }
 template <int PX> __device__ __forceinline__ void stv(float *p, const PxV<PX> &a) {
   if (PX == 4) { f32x4 t = {a.v[0], a.v[1 % PX], a.v[2 % PX], a.v[3 % PX]}; *reinterpret_cast<f32x4 *>(p) = t; }
+  else if (PX == 2) { tcl_f2 t = {a.v[0], a.v[1 % PX]}; *reinterpret_cast<tcl_f2 *>(p) = t; }
   else p[0] = a.v[0];
 }
 
@@ -99,6 +101,127 @@ __global__ void __launch_bounds__(64 * NCG) corr_normalise_kernel(const float *_
     }
   }
   if (cg == 0) stv<PX>(nrm + (int64_t)bf * P + p, nn);
+}
+
+// C <= NCG * KU: the thread's KU channels stay in registers between the norm and the scaling, so x is read once
+// (the two-loop kernel fetched 1.5x the algorithmic bytes at C2: its second walk missed L2).  Same operation order.
+template <int PX, int NCG, int KU>
+__global__ void __launch_bounds__(64 * NCG) corr_normalise_keep_kernel(const float *__restrict__ x, const float *__restrict__ v,
+                                                                  float *__restrict__ hat, float *__restrict__ nrm, int C, int F, int P) {
+  const int bf = blockIdx.y, b = bf / F, f = bf - b * F;
+  const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int p0 = (blockIdx.x * 64 + lane) * PX;
+  const bool ok = p0 < P;
+  const int p = ok ? p0 : 0;
+  PxV<PX> m;
+#pragma unroll
+  for (int e = 0; e < PX; ++e) m.v[e] = 1.f;
+  if (v) m = ldv<PX>(v + (int64_t)bf * P + p);
+  const float *xp = x + ((int64_t)b * C * F + f) * P + p;
+  const int64_t cs = (int64_t)F * P;
+  PxV<PX> t[KU];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) t[u] = ldv<PX>(xp + min(cg + NCG * u, C - 1) * cs);
+  TCL_LOADS_FIRST(KU);
+  float ss[PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) ss[e] = 0.f;
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+    const float live = cg + NCG * u < C ? 1.f : 0.f;
+#pragma unroll
+    for (int e = 0; e < PX; ++e) {
+      t[u].v[e] = t[u].v[e] * m.v[e];
+      const float q = t[u].v[e] * live;
+      ss[e] += q * q;
+    }
+  }
+  __shared__ float red[NCG][64 * PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) red[cg][lane * PX + e] = ss[e];
+  __syncthreads();
+  float den[PX];
+  PxV<PX> nn;
+#pragma unroll
+  for (int e = 0; e < PX; ++e) {
+    const int l = lane * PX + e;
+    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) t4[g & 3] += red[g][l];
+    nn.v[e] = sqrtf((t4[0] + t4[1]) + (t4[2] + t4[3]));
+    den[e] = nn.v[e] + kNormEps;
+  }
+  if (!ok) return;
+  float *hp = hat + (int64_t)bf * C * P + p;
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+#pragma unroll
+    for (int e = 0; e < PX; ++e) t[u].v[e] = t[u].v[e] / den[e];
+    if (cg + NCG * u < C) stv<PX>(hp + (int64_t)(cg + NCG * u) * P, t[u]);
+  }
+  if (cg == 0) stv<PX>(nrm + (int64_t)bf * P + p, nn);
+}
+
+template <int PX, int NCG, int KU>
+__global__ void __launch_bounds__(64 * NCG) corr_normalise_bwd_keep_kernel(const float *__restrict__ x, const float *__restrict__ v,
+                                                                      const float *__restrict__ dhat, const float *__restrict__ nrm,
+                                                                      float *__restrict__ gx, int C, int F, int P) {
+  const int bf = blockIdx.y, b = bf / F, f = bf - b * F;
+  const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int p0 = (blockIdx.x * 64 + lane) * PX;
+  const bool ok = p0 < P;
+  const int p = ok ? p0 : 0;
+  PxV<PX> m;
+#pragma unroll
+  for (int e = 0; e < PX; ++e) m.v[e] = 1.f;
+  if (v) m = ldv<PX>(v + (int64_t)bf * P + p);
+  const float *xp = x + ((int64_t)b * C * F + f) * P + p;
+  const float *dp = dhat + (int64_t)bf * C * P + p;
+  const int64_t cs = (int64_t)F * P;
+  PxV<PX> t[KU], d[KU];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+    const int c = min(cg + NCG * u, C - 1);
+    t[u] = ldv<PX>(xp + c * cs);
+    d[u] = ldv<PX>(dp + (int64_t)c * P);
+  }
+  const PxV<PX> n = ldv<PX>(nrm + (int64_t)bf * P + p);
+  TCL_LOADS_FIRST(2 * KU + 1);
+  float dot[PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) dot[e] = 0.f;
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+    const float live = cg + NCG * u < C ? 1.f : 0.f;
+#pragma unroll
+    for (int e = 0; e < PX; ++e) {
+      t[u].v[e] = t[u].v[e] * m.v[e];
+      dot[e] += (d[u].v[e] * t[u].v[e]) * live;
+    }
+  }
+  __shared__ float red[NCG][64 * PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) red[cg][lane * PX + e] = dot[e];
+  __syncthreads();
+  float ne[PX], k[PX];
+#pragma unroll
+  for (int e = 0; e < PX; ++e) {
+    const int l = lane * PX + e;
+    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) t4[g & 3] += red[g][l];
+    const float dt = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    ne[e] = n.v[e] + kNormEps;
+    k[e] = n.v[e] > 0.f ? dt / (ne[e] * ne[e] * n.v[e]) : 0.f;
+  }
+  if (!ok) return;
+  float *gp = gx + ((int64_t)b * C * F + f) * P + p;
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+#pragma unroll
+    for (int e = 0; e < PX; ++e) d[u].v[e] = (d[u].v[e] / ne[e] - t[u].v[e] * k[e]) * m.v[e];
+    if (cg + NCG * u < C) stv<PX>(gp + (cg + NCG * u) * cs, d[u]);
+  }
 }
 
 // Jacobian of the normalisation: g_x = v * (d_hat/(n+eps) - t * <d_hat,t> / ((n+eps)^2 n)),  0-norm -> first term only.
@@ -870,7 +993,16 @@ static bool norm_vec_ok(int64_t P, const void *a, const void *b, const void *c, 
   return P % 4 == 0 && aligned(a, 16) && aligned(b, 16) && aligned(c, 16) && aligned(d, 16) && aligned(e, 16);
 }
 static void launch_normalise(hipStream_t s, const float *x, const float *v, float *hat, float *nrm, int64_t BF, int C, int F, int64_t P) {
-  if (!norm_vec_ok(P, x, v, hat, nrm, nullptr))
+  static const bool keep = getenv("TCL_NORM_NO_KEEP") == nullptr;   // A/B switch
+  const bool vec = norm_vec_ok(P, x, v, hat, nrm, nullptr);
+#define TCL_NORM_KEEP(NCG) hipLaunchKernelGGL((corr_normalise_keep_kernel<2, NCG, 16>), dim3((unsigned)cdiv(P, 128), (unsigned)BF), dim3(64 * NCG), 0, s, x, v, hat, nrm, C, F, (int)P)
+  if (vec && keep && C <= 256) {   // single read of x: the thread's <= 16 channels stay in registers
+    if (C <= 64) TCL_NORM_KEEP(4);
+    else if (C <= 128) TCL_NORM_KEEP(8);
+    else TCL_NORM_KEEP(16);
+  } else
+#undef TCL_NORM_KEEP
+  if (!vec)
     hipLaunchKernelGGL((corr_normalise_kernel<1, 4>), dim3((unsigned)cdiv(P, 64), (unsigned)BF), dim3(256), 0, s, x, v, hat, nrm, C, F, (int)P);
   else if (cdiv(P, 256) * BF >= 4 * kNumCU || C < 128)   // enough blocks: 4 waves each; else 16 waves share the channels
     hipLaunchKernelGGL((corr_normalise_kernel<4, 4>), dim3((unsigned)cdiv(P, 256), (unsigned)BF), dim3(256), 0, s, x, v, hat, nrm, C, F, (int)P);
@@ -879,7 +1011,16 @@ static void launch_normalise(hipStream_t s, const float *x, const float *v, floa
 }
 static void launch_normalise_bwd(hipStream_t s, const float *x, const float *v, const float *dhat, const float *nrm, float *gx, int64_t BF,
                                  int C, int F, int64_t P) {
-  if (!norm_vec_ok(P, x, v, dhat, nrm, gx))
+  static const bool keep = getenv("TCL_NORM_NO_KEEP") == nullptr;
+  const bool vec = norm_vec_ok(P, x, v, dhat, nrm, gx);
+#define TCL_NORM_KEEP(NCG) hipLaunchKernelGGL((corr_normalise_bwd_keep_kernel<2, NCG, 16>), dim3((unsigned)cdiv(P, 128), (unsigned)BF), dim3(64 * NCG), 0, s, x, v, dhat, nrm, gx, C, F, (int)P)
+  if (vec && keep && C <= 256) {   // x and d_hat read once; two pixels per lane so that 2 x 16 channels fit the register budget
+    if (C <= 64) TCL_NORM_KEEP(4);
+    else if (C <= 128) TCL_NORM_KEEP(8);
+    else TCL_NORM_KEEP(16);
+  } else
+#undef TCL_NORM_KEEP
+  if (!vec)
     hipLaunchKernelGGL((corr_normalise_bwd_kernel<1, 4>), dim3((unsigned)cdiv(P, 64), (unsigned)BF), dim3(256), 0, s, x, v, dhat, nrm, gx, C, F, (int)P);
   else if (cdiv(P, 256) * BF >= 4 * kNumCU || C < 128)
     hipLaunchKernelGGL((corr_normalise_bwd_kernel<4, 4>), dim3((unsigned)cdiv(P, 256), (unsigned)BF), dim3(256), 0, s, x, v, dhat, nrm, gx, C, F, (int)P);
