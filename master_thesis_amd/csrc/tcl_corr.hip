@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
     la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
     lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
   }
-  constexpr bool PIPE = !A_KC && !B_KC && EPI == EPI_STORE;   // hand-pipelined fragment reads, permuted LDS rows
+  constexpr bool PIPE = !A_KC && !B_KC;   // hand-pipelined fragment reads, permuted LDS rows
   for (int t = 0; t < total; ++t) {
     la.template store<PIPE ? WM : 0>(As, tid);
     lb.template store<PIPE ? WN : 0>(Bs, tid);
@@ -525,40 +525,39 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = EPI == EPI_STORE ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0)   // transposed tile, see the epilogue
-                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // transposed tile, see the epilogues
     }
     __syncthreads();
   }
 
-  // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The tiles were accumulated
+  // transposed (B fragment as the MFMA's A operand): a lane holds ONE row m of D and, in register quad q, the four
+  // consecutive columns n = 8 q + 4 (lane >> 5) + e.
   if (EPI == EPI_ARGMAX) {
+    // A row's maximum is therefore an in-register scan over the lane's TN * 16 columns (ascending n, strict '>' keeps the
+    // first maximum), one exchange with the other lane half and one LDS step across the WN waves of the row.
     // smem is free again (the loop ended on a barrier): [BM][WN] (value, column) pairs
     float2 *best = reinterpret_cast<float2 *>(smem);
     static_assert(BM * WN * 2 <= A_LDS + B_LDS, "argmax scratch must fit the staging buffer");
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + wn0 + j * 32 + lr;
-          const float v = acc[i][j][r];
-          if (n < g.N && (v > bv || bi == 0x7fffffff)) { bv = v; bi = n; }
-        }
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {  // across the 32 lanes of this half (same row)
-          const float ov = __shfl_xor(bv, o, 64);
-          const int oi = __shfl_xor(bi, o, 64);
-          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        if (lr == 0) {
-          const int ml = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          best[ml * WN + (wid % WN)] = make_float2(bv, __int_as_float(bi));
-        }
-      }
+          for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wn0 + j * 32 + 8 * q + 4 * lh + e;
+            const float v = acc[i][j][4 * q + e];
+            if (n < g.N && (v > bv || bi == 0x7fffffff)) { bv = v; bi = n; }
+          }
+      const float ov = __shfl_xor(bv, 32, 64);
+      const int oi = __shfl_xor(bi, 32, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      if (lh == 0) best[(wm0 + i * 32 + lr) * WN + (wid % WN)] = make_float2(bv, __int_as_float(bi));
+    }
     __syncthreads();
     for (int ml = tid; ml < BM; ml += NT) {
       const int m = m0 + ml;
