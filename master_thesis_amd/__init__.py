@@ -50,6 +50,13 @@ def install_dropin(reference_modules=None):
         for sym in symbols:
             setattr(target, sym, getattr(src, sym))
             patched.append("%s.%s" % (name, sym))
+    # CPNet keeps its own conv stacks and weights; its two hot methods are rebound so that the affine warp and (through the
+    # patched CPNContextMatchingDefault of new instances) the context matching run on the HIP kernels
+    ref_cpn = mods.get("models.cpn")
+    if ref_cpn is not None and hasattr(ref_cpn, "CPNet"):
+        for meth in ("align", "copy_and_paste"):
+            setattr(ref_cpn.CPNet, meth, getattr(_cpn.CPNet, meth))
+            patched.append("models.cpn.CPNet.%s" % meth)
     # the sequence schedulers (static methods of the runner classes), if those modules are loaded: same signatures,
     # and `schedulers.*_batched` is then available to callers that hold several sequences
     from . import schedulers as _sched

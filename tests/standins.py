@@ -97,3 +97,32 @@ def moving_hole_sequence(seed, c, f, h, w, hole, step):
     if seed % 2 == 1:
         m[0, :, h - 4:h - 1, w - 4:w - 1] = 1
     return x, m
+
+
+# ---- CPNet golden (tests/golden/make_golden_cpnet.py and tests/test_cpnet.py share these)
+CPNET_SEED = 11
+
+
+def cpnet_package_net():
+    """This package's CPNet('full') with seeded weights: theta away from the identity (shifts of a few pixels), and a
+    variance-preserving init of the encoder / decoder (with torch's default one y_hat is set by the biases alone)."""
+    import torch
+    from master_thesis_amd.models import cpn as my_cpn
+    torch.manual_seed(CPNET_SEED)
+    net = my_cpn.CPNet('full')
+    with torch.no_grad():
+        net.alignment_regressor.fc.weight.mul_(0.5)
+        for mod in list(net.encoder.modules()) + list(net.decoder.modules()):
+            if isinstance(mod, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(mod.weight, nonlinearity='relu')
+    return net.eval()
+
+
+def cpnet_inputs():
+    import torch
+    g = torch.Generator().manual_seed(CPNET_SEED + 1)
+    B, F_, H, W = 1, 3, 64, 64
+    x = torch.rand(B, 3, F_, H, W, generator=g)
+    y = torch.rand(B, 3, F_, H, W, generator=g)
+    m = (torch.rand(B, 1, F_, H // 8, W // 8, generator=g) < 0.25).float().repeat_interleave(8, 3).repeat_interleave(8, 4)
+    return x * (1 - m), m, y, 1, [0, 2]
