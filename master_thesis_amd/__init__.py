@@ -6,7 +6,8 @@ The sub-modules mirror the reference's module and function names for this path:
 
     master_thesis_amd.utils.correlation   <- utils/correlation.py
     master_thesis_amd.utils.flow          <- utils/flow.py
-    master_thesis_amd.models.cpn          <- the hot-path parts of models/cpn.py
+    master_thesis_amd.models.cpn          <- models/cpn.py (context matching, helpers, CPNet around the HIP warp + matching)
+    master_thesis_amd.models.thesis_alignment <- models/thesis_alignment.py (the alignment network around the HIP cost volume)
     master_thesis_amd.models.cpn_original <- CM_Module of models/cpn_original.py
     master_thesis_amd.utils.movement      <- utils/movement.py (on the device)
     master_thesis_amd.runners / schedulers <- the static step functions and sequence schedulers of the three runners

@@ -126,3 +126,35 @@ def cpnet_inputs():
     y = torch.rand(B, 3, F_, H, W, generator=g)
     m = (torch.rand(B, 1, F_, H // 8, W // 8, generator=g) < 0.25).float().repeat_interleave(8, 3).repeat_interleave(8, 4)
     return x * (1 - m), m, y, 1, [0, 2]
+
+
+# ---- ThesisAlignmentModel golden (tests/golden/make_golden_alignment_model.py and tests/test_alignment_model.py)
+ALIGN_SEED = 23
+
+
+def alignment_package_net():
+    """This package's ThesisAlignmentModel around the seeded stand-in feature extractor, variance-preserving init
+    for the conv stacks (with torch's default one the flows are set by the biases alone)."""
+    import torch
+    from master_thesis_amd import harness_c3
+    from master_thesis_amd.models import thesis_alignment as ta
+    torch.manual_seed(ALIGN_SEED)
+    net = ta.ThesisAlignmentModel(harness_c3.FeatureStandIn())
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                torch.nn.init.kaiming_normal_(mod.weight, nonlinearity='relu')
+        for stack in (net.corr_mixer.mixer, net.flow_64.nn, net.flow_256.nn):   # flows of moderate size
+            stack[-1].weight.mul_(0.1)
+    return net.eval()
+
+
+def alignment_inputs():
+    import torch
+    g = torch.Generator().manual_seed(ALIGN_SEED + 1)
+    B, R, H, W = 1, 2, 64, 96
+    x_target = torch.rand(B, 3, H, W, generator=g)
+    x_refs = torch.rand(B, 3, R, H, W, generator=g)
+    m_target = (torch.rand(B, 1, H // 16, W // 16, generator=g) < 0.2).float().repeat_interleave(16, 2).repeat_interleave(16, 3)
+    m_refs = (torch.rand(B, 1, R, H // 16, W // 16, generator=g) < 0.2).float().repeat_interleave(16, 3).repeat_interleave(16, 4)
+    return x_target * (1 - m_target), m_target, x_refs * (1 - m_refs), m_refs
