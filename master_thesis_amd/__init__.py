@@ -8,7 +8,7 @@ The sub-modules mirror the reference's module and function names for this path:
     master_thesis_amd.utils.flow          <- utils/flow.py
     master_thesis_amd.models.cpn          <- models/cpn.py (context matching, helpers, CPNet around the HIP warp + matching)
     master_thesis_amd.models.thesis_alignment <- models/thesis_alignment.py (the alignment network around the HIP cost volume)
-    master_thesis_amd.models.cpn_original <- CM_Module of models/cpn_original.py
+    master_thesis_amd.models.cpn_original <- models/cpn_original.py (CM_Module; CPNOriginal around the HIP warp + matching)
     master_thesis_amd.utils.movement      <- utils/movement.py (on the device)
     master_thesis_amd.runners / schedulers <- the static step functions and sequence schedulers of the three runners
 
@@ -58,6 +58,11 @@ def install_dropin(reference_modules=None):
         for meth in ("align", "copy_and_paste"):
             setattr(ref_cpn.CPNet, meth, getattr(_cpn.CPNet, meth))
             patched.append("models.cpn.CPNet.%s" % meth)
+    ref_cpo = mods.get("models.cpn_original")
+    if ref_cpo is not None and hasattr(ref_cpo, "CPNOriginal"):   # same for the original network (what thesis_cpn runs)
+        for meth in ("align", "copy_and_paste"):
+            setattr(ref_cpo.CPNOriginal, meth, getattr(_cpo.CPNOriginal, meth))
+            patched.append("models.cpn_original.CPNOriginal.%s" % meth)
     # the sequence schedulers (static methods of the runner classes), if those modules are loaded: same signatures,
     # and `schedulers.*_batched` is then available to callers that hold several sequences
     from . import schedulers as _sched

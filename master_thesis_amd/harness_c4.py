@@ -1,14 +1,14 @@
 """Harness for BASELINE.json configs[3] (C4): copy-and-paste inference around the HIP hot path.
 
-  alignment   -> `CopyPasteNet.align`: alignment encoder + regressor (stock convolutions) -> theta; then the affine warp of
+  alignment   -> `CPNOriginal.align`: alignment encoder + regressor (stock convolutions) -> theta; then the affine warp of
                  frames and visibility maps on the HIP kernel (`models.cpn.affine_align`, grid never materialised) and `v_map`
   copy        -> copy encoder (stock convolutions, stride 4: 240 x 424 -> 60 x 106 x 128) -> `models.cpn_original.CM_Module`
                  on the HIP context-matching kernels (similarity, masked softmax over the references, aggregation)
   paste       -> decoder with the dilated block (stock convolutions)
 
-The network restates the layer structure of CPNOriginal (models/cpn_original.py:52-183, 246-315) on stock torch
-convolutions; the pretrained weights (weights/cpn/cpn.pth) are not loaded (random init, the regressor's last layer is
-perturbed so that the thetas are not all the identity).  The reference only runs this network in inference
+The network is `models.cpn_original.CPNOriginal` of this package (the reference's layer structure, models/cpn_original.py:52-183,
+246-315, on stock torch convolutions, state_dict-compatible); the pretrained weights (weights/cpn/cpn.pth) are not available
+offline (random init, the regressor's last layer is perturbed so that the thetas are not all the identity).  The reference only runs this network in inference
 (thesis_cpn/runner.py:59-60 raises in train_step), so this harness is forward-only.
 
 Run:  python -m master_thesis_amd.harness_c4 --targets 4 --refs 10
@@ -18,76 +18,17 @@ import json
 import time
 
 import torch
-import torch.nn as nn
-import torch.nn.functional as F
 
-from . import _ops
 from .models import cpn, cpn_original
 
 
-def convs(spec, in_c):
-    """spec: (out_c, kernel, stride, dilation, relu)"""
-    layers, c = [], in_c
-    for oc, k, st, d, relu in spec:
-        layers.append(nn.Conv2d(c, oc, k, stride=st, padding=d * (k // 2), dilation=d))
-        if relu:
-            layers.append(nn.ReLU())
-        c = oc
-    return nn.Sequential(*layers)
-
-
-class CopyPasteNet(nn.Module):
-    def __init__(self):
-        super().__init__()
-        self.a_encoder = convs([(64, 5, 2, 1, 1), (64, 3, 1, 1, 1), (128, 3, 2, 1, 1), (128, 3, 1, 1, 1), (256, 3, 2, 1, 1), (256, 3, 1, 1, 1), (256, 3, 1, 1, 1)], 4)
-        self.a_reg_down1 = convs([(512, 3, 2, 1, 1)], 512)
-        self.a_reg_body = convs([(512, 3, 1, 1, 1), (512, 3, 1, 1, 1)], 512)     # applied after each downsampling, as the reference does
-        self.a_reg_down2 = convs([(512, 3, 2, 1, 1)], 512)
-        self.fc = nn.Linear(512, 6)
-        with torch.no_grad():
-            self.fc.weight.normal_(0, 2e-3)
-            self.fc.bias.copy_(torch.tensor([1., 0, 0, 0, 1, 0]))
-        self.encoder = convs([(64, 5, 2, 1, 1), (64, 3, 1, 1, 1), (128, 3, 2, 1, 1), (128, 3, 1, 1, 1), (128, 3, 1, 1, 0)], 4)
-        self.cm = cpn_original.CM_Module()
-        self.dec_low = convs([(257, 3, 1, 1, 1)] * 3 + [(257, 3, 1, 2, 1), (257, 3, 1, 4, 1), (257, 3, 1, 8, 1), (257, 3, 1, 16, 1)] +
-                             [(257, 3, 1, 1, 1), (128, 3, 1, 1, 1), (128, 3, 1, 1, 1)], 257)
-        self.dec_mid = convs([(64, 3, 1, 1, 1), (64, 3, 1, 1, 1)], 128)
-        self.dec_out = convs([(3, 5, 1, 1, 0)], 64)
-        self.register_buffer('mean', torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
-        self.register_buffer('std', torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
-
-    def _a_feats(self, f, v):
-        x = torch.cat([(f - self.mean) / self.std, v], dim=1)
-        return self.a_encoder(F.interpolate(x, size=(224, 224), mode='bilinear', align_corners=False))
-
-    def align(self, x_target, m_target, x_refs, m_refs):
-        """-> (x_aligned (B,3,R,H,W), v_aligned (B,1,R,H,W), v_maps).  models/cpn_original.py:260-290."""
-        b, c, r, h, w = x_refs.size()
-        ft = self._a_feats(x_target, m_target)
-        fr = self._a_feats(x_refs.transpose(1, 2).reshape(-1, c, h, w), m_refs.transpose(1, 2).reshape(-1, 1, h, w))
-        pair = torch.cat([ft.unsqueeze(1).expand(b, r, *ft.shape[1:]).reshape(b * r, *ft.shape[1:]), fr], dim=1)
-        x = self.a_reg_body(self.a_reg_down2(self.a_reg_body(self.a_reg_down1(pair))))
-        theta = self.fc(F.avg_pool2d(x, x.shape[2]).flatten(1)).view(-1, 2, 3)
-        x_aligned, v_aligned, _ = cpn.affine_align(x_refs, m_refs, None, theta.float(), list(range(r)))   # HIP warp
-        return x_aligned, v_aligned, _ops.vmap(v_aligned, 1 - m_target)
-
-    def copy_and_paste(self, x_target, v_target, x_aligned, v_aligned):
-        """models/cpn_original.py:292-315."""
-        b, c, r, h, w = x_aligned.size()
-        frames = torch.cat([x_target.unsqueeze(2), x_aligned], dim=2).transpose(1, 2).reshape(-1, c, h, w)
-        masks = torch.cat([1 - v_target.unsqueeze(2), v_aligned], dim=2).transpose(1, 2).reshape(-1, 1, h, w)
-        feats = self.encoder(torch.cat([(frames - self.mean) / self.std, masks], dim=1))
-        feats = feats.reshape(b, r + 1, *feats.shape[1:]).transpose(1, 2).float()
-        p_in, c_mask = self.cm(feats, v_target, v_aligned)                                                # HIP context matching
-        x = self.dec_low(p_in)
-        x = self.dec_mid(F.interpolate(x, scale_factor=2, mode='nearest'))
-        x = self.dec_out(F.interpolate(x, scale_factor=2, mode='nearest'))
-        y_hat = torch.clamp(x * self.std + self.mean, 0, 1)
-        return y_hat, v_target * x_target + (1 - v_target) * y_hat
-
-    def forward(self, x_target, m_target, x_refs, m_refs):
-        x_aligned, v_aligned, _ = self.align(x_target, m_target, x_refs, m_refs)
-        return self.copy_and_paste(x_target, 1 - m_target, x_aligned, v_aligned)
+def CopyPasteNet():
+    """The drop-in network (models.cpn_original.CPNOriginal, pinned against the reference's forward by
+    tests/golden/cpn_original.npz) with the regressor's last layer perturbed so that the thetas are not all the identity."""
+    net = cpn_original.CPNOriginal()
+    with torch.no_grad():
+        net.A_Regressor.fc.weight.normal_(0, 2e-3)
+    return net
 
 
 def main():
@@ -128,7 +69,7 @@ def main():
         e0.record()
         for _ in range(5):
             cpn.affine_align(x[:, :, r_list], m[:, :, r_list], None, theta, list(range(R)))
-            net.cm(feats, 1 - m[:, :, t], va)
+            net.CM_Module(feats, 1 - m[:, :, t], va)
         e1.record()
         e1.synchronize()
     print(json.dumps({"workload": "C4: copy-and-paste inference, %dx%d, %d references" % (H, W, R), "targets_per_step": B,

@@ -158,3 +158,33 @@ def alignment_inputs():
     m_target = (torch.rand(B, 1, H // 16, W // 16, generator=g) < 0.2).float().repeat_interleave(16, 2).repeat_interleave(16, 3)
     m_refs = (torch.rand(B, 1, R, H // 16, W // 16, generator=g) < 0.2).float().repeat_interleave(16, 3).repeat_interleave(16, 4)
     return x_target * (1 - m_target), m_target, x_refs * (1 - m_refs), m_refs
+
+
+# ---- CPNOriginal golden (tests/golden/make_golden_cpn_original.py and tests/test_cpn_original.py)
+CPNO_SEED = 31
+
+
+def cpn_original_package_net():
+    """This package's CPNOriginal with seeded weights; the regressor's last layer (zero in a fresh net = identity theta) is
+    perturbed so that the warp does something, the decoder gets a variance-preserving init."""
+    import torch
+    from master_thesis_amd.models import cpn_original as my
+    torch.manual_seed(CPNO_SEED)
+    net = my.CPNOriginal()
+    with torch.no_grad():
+        net.A_Regressor.fc.weight.normal_(0, 0.01)
+        for mod in net.Decoder.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(mod.weight, nonlinearity='relu')
+    return net.eval()
+
+
+def cpn_original_inputs():
+    import torch
+    g = torch.Generator().manual_seed(CPNO_SEED + 1)
+    B, R, H, W = 2, 3, 48, 64
+    x_target = torch.rand(B, 3, H, W, generator=g)
+    x_refs = torch.rand(B, 3, R, H, W, generator=g)
+    m_target = (torch.rand(B, 1, H // 8, W // 8, generator=g) < 0.25).float().repeat_interleave(8, 2).repeat_interleave(8, 3)
+    m_refs = (torch.rand(B, 1, R, H // 8, W // 8, generator=g) < 0.25).float().repeat_interleave(8, 3).repeat_interleave(8, 4)
+    return x_target * (1 - m_target), m_target, x_refs * (1 - m_refs), m_refs

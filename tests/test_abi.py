@@ -92,7 +92,9 @@ def test_install_dropin_patches_reference_names():
     assert fake["thesis_inpainting.runner"].ThesisInpaintingRunner.inpainting_algorithm_ff_indexes(2, 5, 1, 20) == [1, 3, 0, 4]
     assert fake["thesis_cpn.runner"].ThesisCPNRunner.get_reference_frame_indexes(0, 5) == [2]
     # CPNet of the reference, when present, gets the two hot methods; its conv stacks and weights stay its own
+    fake["models.cpn_original"].CPNOriginal = type("CPNOriginal", (), {})
     fake["models.cpn"].CPNet = type("CPNet", (), {})
     patched = m.install_dropin(fake)
     assert "models.cpn.CPNet.align" in patched and "models.cpn.CPNet.copy_and_paste" in patched
     assert fake["models.cpn"].CPNet.align is m.models.cpn.CPNet.align
+    assert fake["models.cpn_original"].CPNOriginal.copy_and_paste is m.models.cpn_original.CPNOriginal.copy_and_paste

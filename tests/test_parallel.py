@@ -115,7 +115,9 @@ def test_c3_network_matches_the_reference_layer_shapes():
 
 
 def test_c4_network_matches_the_reference_parameter_count():
-    """CopyPasteNet restates CPNOriginal (models/cpn_original.py): 21,631,385 parameters in the reference, of which the
-    4,719,616 of A_Regressor.conv6a / conv6b are never used by its forward (it re-applies conv5a / conv5b, :103-104)."""
+    """The C4 harness runs models.cpn_original.CPNOriginal of this package: 21,631,385 parameters as in the reference, of which
+    the 4,719,616 of A_Regressor.conv6a / conv6b are held but never applied (its forward re-applies conv5a / conv5b, :103-104)."""
     from master_thesis_amd import harness_c4
-    assert sum(p.numel() for p in harness_c4.CopyPasteNet().parameters()) == 21631385 - 4719616
+    net = harness_c4.CopyPasteNet()
+    assert sum(p.numel() for p in net.parameters()) == 21631385
+    assert sum(p.numel() for n, p in net.named_parameters() if "conv6" in n) == 4719616
