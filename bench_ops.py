@@ -21,10 +21,29 @@ PEAK_F32_TF = 157.3
 DEV = "cuda:0"
 
 
+COLD = False      # --cold: evict L2 and the 256 MB Infinity Cache before every timed call
+_flush = None
+
+
 def timed(fn, iters, warm=3):
     for _ in range(warm):
         fn()
     s = torch.cuda.current_stream()
+    if COLD:
+        # One event pair per call, a read of 1 GiB in front of each: the working sets of C3 / C4 (0.3 - 1 GB) would
+        # otherwise be partly served from the Infinity Cache between iterations.  The flush takes ~0.4 ms on the GPU, so the
+        # host enqueues the next call's kernels while it runs and no launch gap lands inside the event pair.
+        global _flush
+        if _flush is None:
+            _flush = torch.zeros(1 << 28, dtype=torch.float32, device=DEV)
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for e0, e1 in pairs:
+            _flush.sum()   # read-only on purpose: a writing flush leaves 256 MB of dirty lines whose write-back the timed kernel then pays
+            e0.record(s)
+            fn()
+            e1.record(s)
+        pairs[-1][1].synchronize()
+        return sum(e0.elapsed_time(e1) for e0, e1 in pairs) / iters
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s)
     for _ in range(iters):
@@ -46,6 +65,8 @@ def report(name, ms, bytes_=None, flops=None, units=None, unit_name="pairs", not
         r["%s_per_s" % unit_name] = round(units / (ms * 1e-3), 1)
     if note:
         r["note"] = note
+    if COLD:
+        r["cache"] = "cold (1 GiB read before every call)"
     print(json.dumps(r), flush=True)
 
 
@@ -270,7 +291,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ops", default="warp,affine,ctx,corr_model,argmax")
+    ap.add_argument("--cold", action="store_true", help="flush L2 / Infinity Cache before every timed call")
     a = ap.parse_args()
+    global COLD
+    COLD = a.cold
     torch.cuda.set_device(0)
     table = dict(misc=bench_misc, movement=bench_movement, sched=bench_sched, warp=bench_warp, affine=bench_affine, ctx=bench_ctx, corr_model=bench_corr_model, argmax=bench_argmax, cpu=bench_cpu)
     for op in a.ops.split(","):

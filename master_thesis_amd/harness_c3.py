@@ -7,9 +7,10 @@ the share of the hot path in a real step can be measured:
                        uses pretrained VGG-16 weights (models/vgg_16.py) that are not available offline; SURVEY.md §8d
                        prescribes the seeded stand-in.
   cost volume       -> `utils.correlation.compute_masked_4d_correlation` on the HIP kernels (A1), 16 x 16 x 512
-  the network       -> `AlignmentNet`: the layer structure of ThesisAlignmentModel (models/thesis_alignment.py:8-225:
-                       separable 4-D convolution over the volume, correlation mixer, two flow estimators) restated on stock
-                       torch convolutions (MIOpen); bf16 autocast for them in C3, the volume and the warps stay fp32
+  the network       -> `models.thesis_alignment.ThesisAlignmentModel` of this package (the reference's layer structure,
+                       models/thesis_alignment.py:8-225: separable 4-D convolution over the volume, correlation mixer, two flow
+                       estimators, on stock torch convolutions, state_dict-compatible); bf16 autocast for the convolutions in
+                       C3, the volume and the warps stay fp32
   after the network -> `runners.train_step_propagate`: six `align_set` warps at 16 / 64 / 256 px, two `resize_flow`s, `v_map`s
   loss              -> `alignment_loss`: the terms of ThesisAlignmentRunner.compute_loss (thesis_dfpn/runner.py:161-206)
 
@@ -27,6 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import runners
+from .models import thesis_alignment
 from .utils import correlation
 from .utils.losses import LossesUtils
 
@@ -61,80 +63,10 @@ class FeatureStandIn(nn.Module):
         return [None, None, None, self.body(x)]
 
 
-class SeparableConv4d(nn.Module):
-    """Two 2-D conv stacks over a (b,t,h,w,h,w) volume: first over the reference-pixel plane of every target pixel, then
-    over the target-pixel plane of every reference pixel.  models/thesis_alignment.py:8-36."""
-
-    def __init__(self):
-        super().__init__()
-        self.conv_1 = conv_stack([(128, 3, 1), (256, 3, 1), (256, 3, 1)], 1, final_relu=False)
-        self.conv_2 = conv_stack([(256, 3, 1), (128, 3, 1), (1, 3, 1)], 256, final_relu=False)
-
-    def forward(self, corr):
-        b, t, h, w = corr.shape[:4]
-        x = self.conv_1(corr.reshape(b * t * h * w, 1, h, w))                       # per target pixel, over reference pixels
-        x = x.reshape(b, t, h * w, x.size(1), h * w).permute(0, 1, 4, 3, 2)         # -> per reference pixel, over target pixels
-        x = self.conv_2(x.reshape(b * t * h * w, x.size(3), h, w))
-        return x.reshape(b, t, h, w, h, w).permute(0, 1, 4, 5, 2, 3)
-
-
-class AlignmentNet(nn.Module):
-    """model(x_target, m_target, x_refs, m_refs) -> (corr, flow_16, flow_64, flow_256).  models/thesis_alignment.py:166-225."""
-    MIXER = [(256, 5, 1), (256, 3, 1), (16, 3, 1), (16, 5, 1), (16, 3, 1), (8, 3, 1), (8, 5, 1), (8, 3, 1), (4, 3, 1), (4, 5, 1), (4, 3, 1)]
-    FLOW = [(128, 5, 1), (128, 3, 1), (128, 5, 2), (128, 5, 1), (128, 3, 1), (128, 3, 2), (128, 5, 1), (128, 3, 1), (128, 3, 2), (128, 5, 1),
-            (128, 3, 1), ('T', 128, 3), (128, 5, 1), (128, 3, 1), ('T', 128, 3), (128, 5, 1), (128, 3, 1), ('T', 128, 5), (128, 5, 1), (128, 3, 1)]
-
-    def __init__(self, features):
-        super().__init__()
-        self.features = features
-        self.conv4d = SeparableConv4d()
-        self.mixer = nn.Sequential(conv_stack(self.MIXER, 256), nn.Conv2d(4, 2, 3, padding=1), nn.Conv2d(2, 2, 5, padding=2), nn.Conv2d(2, 2, 3, padding=1))
-        self.flow_64 = nn.Sequential(conv_stack(self.FLOW, 10), nn.Conv2d(128, 2, 3, padding=1))
-        self.flow_256 = nn.Sequential(conv_stack(self.FLOW, 10), nn.Conv2d(128, 2, 3, padding=1))
-        self.register_buffer('mean', torch.as_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1, 1))
-        self.register_buffer('std', torch.as_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1, 1))
-
-    @staticmethod
-    def resize_data(x_target, m_target, x_ref, m_ref, size):
-        b, c, r, h, w = x_ref.size()
-        if (h, w) == (size, size):
-            return x_target, m_target, x_ref, m_ref
-        frames = lambda t, mode: F.interpolate(t.transpose(1, 2).reshape(b * r, t.size(1), h, w), (size, size), mode=mode) \
-            .reshape(b, r, t.size(1), size, size).transpose(1, 2)
-        return (F.interpolate(x_target, (size, size), mode='bilinear'), F.interpolate(m_target, (size, size), mode='nearest'),
-                frames(x_ref, 'bilinear'), frames(m_ref, 'nearest'))
-
-    @staticmethod
-    def resize_flow_bilinear(flow, h_new, w_new):
-        b, r, h, w, _ = flow.size()
-        return F.interpolate(flow.reshape(b * r, h, w, 2).permute(0, 3, 1, 2).float(), (h_new, w_new), mode='bilinear') \
-            .reshape(b, r, 2, h_new, w_new).permute(0, 1, 3, 4, 2)
-
-    def estimate(self, net, x_target, m_target, x_ref, m_ref, flow_pre):
-        b, c, r, h, w = x_ref.size()
-        rep = lambda t: t.unsqueeze(1).expand(b, r, t.size(1), h, w).reshape(b * r, t.size(1), h, w)
-        per = lambda t: t.transpose(1, 2).reshape(b * r, t.size(1), h, w)
-        inp = torch.cat([per(x_ref), rep(x_target), per(m_ref), rep(m_target), flow_pre.reshape(b * r, h, w, 2).permute(0, 3, 1, 2)], dim=1)
-        return net(inp).float().reshape(b, r, 2, h, w).permute(0, 1, 3, 4, 2)   # flows leave the autocast region as fp32
-
-    def forward(self, x_target, m_target, x_refs, m_refs):
-        b, c, r, h, w = x_refs.size()
-        x_target = (x_target - self.mean.squeeze(2)) / self.std.squeeze(2)
-        x_refs = (x_refs - self.mean) / self.std
-        xt_sq, mt_sq, xr_sq, mr_sq = self.resize_data(x_target, m_target, x_refs, m_refs, 256)
-        with torch.no_grad():
-            ft = self.features(xt_sq)[3]
-            fr = self.features(xr_sq.transpose(1, 2).reshape(b * r, c, 256, 256))[3]
-        fr = fr.reshape(b, r, -1, 16, 16).transpose(1, 2)
-        v_t = F.interpolate(1 - mt_sq, size=(16, 16), mode='nearest')
-        v_r = F.interpolate(1 - mr_sq.transpose(1, 2).reshape(b * r, 1, 256, 256), size=(16, 16), mode='nearest').reshape(b, r, 1, 16, 16).transpose(1, 2)
-        corr = correlation.compute_masked_4d_correlation(ft.float(), v_t.float(), fr.float(), v_r.float())   # the HIP cost volume, fp32
-        corr = self.conv4d(corr)
-        flow_16 = self.mixer(corr.reshape(b * r, 256, 16, 16)).float().reshape(b, r, 2, 16, 16).permute(0, 1, 3, 4, 2)
-        xt_64, mt_64, xr_64, mr_64 = self.resize_data(x_target, m_target, x_refs, m_refs, 64)
-        flow_64 = self.estimate(self.flow_64, xt_64, mt_64, xr_64, mr_64, self.resize_flow_bilinear(flow_16, 64, 64))
-        flow_256 = self.estimate(self.flow_256, xt_sq, mt_sq, xr_sq, mr_sq, self.resize_flow_bilinear(flow_64, 256, 256))
-        return corr, flow_16, flow_64, self.resize_flow_bilinear(flow_256, h, w)
+def AlignmentNet(features):
+    """The drop-in network (models.thesis_alignment.ThesisAlignmentModel of this package, pinned against the reference's
+    forward by tests/golden/alignment_model.npz) around the given feature extractor."""
+    return thesis_alignment.ThesisAlignmentModel(features)
 
 
 def alignment_loss(features, losses, corr, xs, vs, ys, xs_aligned, flows, flows_gt, flows_use, t, r_list):

@@ -40,7 +40,7 @@ class SeparableConv4d(nn.Module):
         x = self.conv_1(corr.reshape(b * t * h * w, -1, h, w))
         x = x.reshape(b, t, h * w, x.size(1), h * w).permute(0, 1, 4, 3, 2)
         x = self.conv_2(x.reshape(b * t * h * w, x.size(3), h, w))
-        return x.reshape(b, t, h, w, h, w).permute(0, 1, 4, 5, 2, 3)
+        return x.float().reshape(b, t, h, w, h, w).permute(0, 1, 4, 5, 2, 3)   # (.float(): a no-op unless the stacks ran under bf16 autocast)
 
 
 class Softmax3d(nn.Module):
@@ -91,7 +91,7 @@ class AlignmentCorrelationMixer(nn.Module):
 
     def forward(self, corr):
         b, f, h, w = corr.shape[:4]
-        return self.mixer(corr.reshape(b * f, -1, 16, 16)).reshape(b, f, 2, h, w).permute(0, 1, 3, 4, 2)
+        return self.mixer(corr.reshape(b * f, -1, 16, 16)).float().reshape(b, f, 2, h, w).permute(0, 1, 3, 4, 2)
 
 
 class FlowEstimator(nn.Module):
@@ -109,7 +109,7 @@ class FlowEstimator(nn.Module):
         per = lambda t: t.transpose(1, 2).reshape(b * ref_n, t.size(1), h, w)
         rep = lambda t: t.unsqueeze(1).expand(b, ref_n, t.size(1), h, w).reshape(b * ref_n, t.size(1), h, w)
         x = torch.cat([per(x_ref), rep(x_target), per(m_ref), rep(m_target), flow_pre.reshape(b * ref_n, h, w, 2).permute(0, 3, 1, 2)], dim=1)
-        return self.nn(x).reshape(b, ref_n, 2, h, w).permute(0, 1, 3, 4, 2)
+        return self.nn(x).float().reshape(b, ref_n, 2, h, w).permute(0, 1, 3, 4, 2)   # flows leave an autocast region as fp32
 
 
 class ThesisAlignmentModel(nn.Module):
@@ -147,5 +147,5 @@ class ThesisAlignmentModel(nn.Module):
 
     def interpolate_flow(self, flow, h_new, w_new):
         b, ref_n, h, w, _ = flow.size()
-        return F.interpolate(flow.reshape(b * ref_n, h, w, 2).permute(0, 3, 1, 2), (h_new, w_new), mode='bilinear') \
+        return F.interpolate(flow.reshape(b * ref_n, h, w, 2).permute(0, 3, 1, 2).float(), (h_new, w_new), mode='bilinear') \
             .reshape(b, ref_n, 2, h_new, w_new).permute(0, 1, 3, 4, 2)

@@ -100,17 +100,17 @@ def test_c5_network_matches_the_reference_parameter_count():
 
 
 def test_c3_network_matches_the_reference_layer_shapes():
-    """AlignmentNet restates ThesisAlignmentModel's trainable stacks.  The counts below are those of the reference's own
-    modules (SeparableConv4d, AlignmentCorrelationMixer, FlowEstimator of models/thesis_alignment.py, instantiated by
-    importing that file in the build container; parameter shapes and order were compared there and are identical)."""
+    """The C3 harness runs models.thesis_alignment.ThesisAlignmentModel of this package.  The counts below are those of the
+    reference's own modules (SeparableConv4d, AlignmentCorrelationMixer, FlowEstimator of models/thesis_alignment.py; the
+    reference class loads this network's state_dict with strict=True, tests/golden/make_golden_alignment_model.py)."""
     from master_thesis_amd import harness_c3
     net = harness_c3.AlignmentNet(harness_c3.FeatureStandIn())
     n = lambda mod: sum(p.numel() for p in mod.parameters())
-    assert (n(net.conv4d), n(net.mixer), n(net.flow_64), n(net.flow_256)) == (1772801, 2278762, 4935682, 4935682)
+    assert (n(net.corr.conv), n(net.corr_mixer), n(net.flow_64), n(net.flow_256)) == (1772801, 2278762, 4935682, 4935682)
     assert sum(p.numel() for p in net.parameters() if p.requires_grad) == 13922927
     vol = torch.rand(1, 2, 4, 4, 4, 4)
-    assert net.conv4d(vol).shape == vol.shape
-    flow = net.resize_flow_bilinear(torch.rand(1, 2, 4, 4, 2), 8, 8)
+    assert net.corr.conv(vol).shape == vol.shape
+    flow = net.interpolate_flow(torch.rand(1, 2, 4, 4, 2), 8, 8)
     assert flow.shape == (1, 2, 8, 8, 2)
 
 
