@@ -531,3 +531,55 @@ def test_graft_entry_smoke_runs():
     """The driver's smoke() (one small invocation of every hot-path op against the oracle) must keep working."""
     import __graft_entry__ as entry
     entry.smoke()
+
+
+# ------------------------------------------------------------------------------------------------ size-independent properties at full size
+def test_align_set_properties_full_size(mods):
+    """C3 size (32 sequences x 4 references, 256 x 256): the identity grid returns the frames (bilinear weights 1 / 0 up to the
+    rounding of the pixel position) and the visibility maps bit-exactly; a grid shifted by exactly one pixel returns the shifted
+    frame with a zero column entering (zeros padding); the warp is linear in x."""
+    g = torch.Generator(device="cpu").manual_seed(17)
+    B, F, S = 32, 4, 256
+    x = torch.rand(B, 3, F, S, S, generator=g).to(DEV)
+    v = (torch.rand(B, 1, F, S // 8, S // 8, generator=g) < 0.8).float().repeat_interleave(8, 3).repeat_interleave(8, 4).to(DEV)
+    lin = torch.linspace(-1, 1, S, device=DEV)
+    ident = torch.stack(torch.meshgrid(lin, lin, indexing="ij")[::-1], dim=-1).expand(B, F, S, S, 2).contiguous()
+    xa, va = mods["flow"].align_set(x, v, ident)
+    assert float((xa - x).abs().max()) <= 1e-4     # the pixel position ((g + 1) / 2) * 255 carries ~3e-5 of rounding
+    assert torch.equal(va, v)
+    shifted = ident.clone()
+    shifted[..., 0] += 2.0 / (S - 1)            # sample one pixel to the right
+    xs, vs = mods["flow"].align_set(x, v, shifted)
+    assert float((xs[..., :-2] - x[..., 1:-1]).abs().max()) <= 1e-4
+    assert float(xs[..., -1].abs().max()) <= 1e-4  # the position S falls outside: zeros (up to the rounding of the position)
+    y = torch.rand(B, 3, F, S, S, generator=g).to(DEV)
+    wob = ident + 0.01 * torch.randn(B, F, 1, 1, 2, generator=g).to(DEV)
+    a, _ = mods["flow"].align_set(x, v, wob)
+    b, _ = mods["flow"].align_set(y, v, wob)
+    ab, _ = mods["flow"].align_set(2 * x - 3 * y, v, wob)
+    assert float((ab - (2 * a - 3 * b)).abs().max()) <= 1e-5
+
+
+def test_context_matching_properties_full_size(mods):
+    """C4 size (32 targets, 128 x 11 x 30 x 53): two runs are bit-identical (fixed summation order, no float atomics); a target
+    processed alone gives the batch's result (different pixel-range split -> tolerance, not bits); the aggregation weights of every
+    pixel sum to one where a reference is visible, so c_mask is in [0, 1] and p_in's first C channels are the target's features."""
+    g = torch.Generator(device="cpu").manual_seed(19)
+    B, C, R, h, w, H, W = 32, 128, 10, 30, 53, 240, 424
+    cf = (0.05 * torch.randn(B, C, R + 1, h, w, generator=g)).to(DEV)
+    v_t = (torch.rand(B, 1, H // 8, W // 8, generator=g) < 0.6).float().repeat_interleave(8, 2).repeat_interleave(8, 3).to(DEV)
+    v_al = (torch.rand(B, 1, R, H // 8, W // 8, generator=g) < 0.7).float().repeat_interleave(8, 3).repeat_interleave(8, 4).to(DEV)
+    mod = mods["cpn"].CPNContextMatchingDefault()
+    p1, m1, r1 = mod(cf, v_t, v_al, normalize=False)
+    p2, m2, r2 = mod(cf, v_t, v_al, normalize=False)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(r1, r2)
+    ps, ms, _ = mod(cf[5:6], v_t[5:6], v_al[5:6], normalize=False)
+    assert float((ps - p1[5:6]).abs().max()) <= 1e-5 and float((ms - m1[5:6]).abs().max()) <= 1e-5
+    assert torch.equal(p1[:, :C], cf[:, :, 0])
+    assert float(m1.min()) >= -1e-6 and float(m1.max()) <= 1.0 + 1e-6
+    assert torch.equal(p1[:, 2 * C:], m1)
+    # a pixel visible in no reference keeps c_mask = 1 and an all-zero aggregated feature
+    none = (torch.nn.functional.interpolate(v_al.reshape(B, R, H, W), size=(h, w), mode="bilinear", align_corners=False) > 0.5).sum(1) == 0
+    assert bool(none.any())
+    assert torch.equal(m1[:, 0][none], torch.ones_like(m1[:, 0][none]))
+    assert float(p1[:, C:2 * C].permute(0, 2, 3, 1)[none].abs().max()) == 0.0
