@@ -122,7 +122,7 @@ def main():
     features = FeatureStandIn().to(dev)
     net = AlignmentNet(features).to(dev)
     params = [p for p in net.parameters() if p.requires_grad]
-    buckets = parallel.GradientBuckets(params)
+    buckets = parallel.GradientBuckets(params, overlap=True)
     opt = torch.optim.Adam(params, lr=1e-4)
     losses = LossesUtils(None, dev)
     hot = {"ms": 0.0}

@@ -136,7 +136,7 @@ def main():
 
     torch.manual_seed(0)
     net = InpaintingNet(nb=args.nb).to(dev)
-    buckets = parallel.GradientBuckets(net.parameters())
+    buckets = parallel.GradientBuckets(net.parameters(), overlap=True)   # all-reduce of a bucket starts under the rest of backward
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     t, r_list = 1, [0]
 

@@ -60,15 +60,22 @@ def gather_shards(local, dim=0):
 
 
 class GradientBuckets:
-    """Bucketed gradient all-reduce for the data-parallel training step (sum over ranks, then / world_size).
+    """Bucketed gradient all-reduce for the data-parallel training step (each rank's gradient / world_size, summed over ranks).
 
     Parameters are packed, in reverse registration order (the order backward produces gradients in), into flat fp32
-    buckets of ~bucket_mb MiB.  `reduce()` launches one asynchronous all-reduce per bucket and `wait()` copies the
-    averaged gradients back, so the collective of bucket k overlaps the packing of bucket k+1.  On 8 x MI355X each
-    GPU has 7 xGMI links of ~153 GB/s; the 58.76 MB gradient of the inpainting network (14,690,883 parameters) is
-    three 25 MiB buckets, each far above the message size where RCCL's ring reaches its per-link bandwidth."""
+    buckets of ~bucket_mb MiB.  On 8 x MI355X each GPU has 7 xGMI links of ~153 GB/s; the 58.76 MB gradient of the
+    inpainting network (14,690,883 parameters) is three 25 MiB buckets, each far above the message size where RCCL's ring
+    reaches its per-link bandwidth.
 
-    def __init__(self, params, bucket_mb=25.0):
+    overlap=False: `reduce()` (after backward) packs every bucket and launches one asynchronous all-reduce per bucket, so the
+        collective of bucket k overlaps the packing of bucket k+1; `wait()` copies the averaged gradients back.
+    overlap=True (built BEFORE backward): every `p.grad` becomes a view into its bucket (no pack / unpack copies) and a
+        post-accumulate hook launches a bucket's all-reduce the moment its last gradient has been accumulated, so the
+        collectives run under the rest of backward; `reduce()` then only launches buckets that backward did not complete
+        (parameters without a gradient count as zeros) and `wait()` only waits.  One backward per reduce()/wait() cycle;
+        use `zero_grad(set_to_none=False)` so that the views survive (a replaced gradient is copied in and out instead)."""
+
+    def __init__(self, params, bucket_mb=25.0, overlap=False):
         self.params = [p for p in params if p.requires_grad]
         limit = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets, cur, cur_n = [], [], 0
@@ -80,39 +87,88 @@ class GradientBuckets:
             cur_n += p.numel()
         if cur:
             self.buckets.append(cur)
-        self._flat = [None] * len(self.buckets)
-        self._handles = []
+        nb = len(self.buckets)
+        self._flat = [None] * nb
+        self._handles = [None] * nb
+        self._launched = [False] * nb
+        self._ready = [0] * nb
+        self.overlap = bool(overlap)
+        self._hooks = []
+        if self.overlap:
+            for i, bucket in enumerate(self.buckets):
+                self._bind(i)
+                for p in bucket:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i)))
+
+    # -- flat storage
+    def _flat_of(self, i):
+        bucket = self.buckets[i]
+        ref = bucket[0]
+        if self._flat[i] is None or self._flat[i].device != ref.device:
+            self._flat[i] = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=ref.device)
+        return self._flat[i]
+
+    def _slots(self, i):
+        flat, off = self._flat_of(i), 0
+        for p in self.buckets[i]:
+            yield p, flat[off:off + p.numel()]
+            off += p.numel()
+
+    @staticmethod
+    def _is_view(p, slot):
+        return p.grad is not None and p.grad.data_ptr() == slot.data_ptr() and p.grad.dtype == slot.dtype and p.grad.is_contiguous()
+
+    def _bind(self, i):
+        for p, slot in self._slots(i):
+            if not self._is_view(p, slot):
+                if p.grad is not None:
+                    slot.copy_(p.grad.reshape(-1))
+                p.grad = slot.view_as(p)
+
+    # -- launching
+    def _on_grad(self, i):
+        self._ready[i] += 1
+        if self._ready[i] == len(self.buckets[i]) and not self._launched[i]:
+            self._launch(i)
+
+    def _launch(self, i):
+        rank, ws = world()
+        flat = self._flat_of(i)
+        for p, slot in self._slots(i):      # gradients that are not views of the bucket: pack them (zeros if absent)
+            if not self._is_view(p, slot):
+                if p.grad is None:
+                    slot.zero_()
+                else:
+                    slot.copy_(p.grad.reshape(-1))
+        if ws > 1:
+            flat.div_(ws)
+            self._handles[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._launched[i] = True
 
     def reduce(self):
-        rank, ws = world()
-        self._handles = []
-        for i, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
-            ref = bucket[0]
-            if self._flat[i] is None or self._flat[i].device != ref.device:
-                self._flat[i] = torch.empty(n, dtype=torch.float32, device=ref.device)
-            flat, off = self._flat[i], 0
-            for p in bucket:
-                g = p.grad if p.grad is not None else torch.zeros_like(p)
-                flat[off:off + p.numel()].copy_(g.reshape(-1))
-                off += p.numel()
-            self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True) if ws > 1 else None)
+        for i in range(len(self.buckets)):
+            if not self._launched[i]:
+                self._launch(i)
         return self
 
     def wait(self):
-        rank, ws = world()
-        for i, bucket in enumerate(self.buckets):
+        for i in range(len(self.buckets)):
             if self._handles[i] is not None:
                 self._handles[i].wait()
-            flat, off = self._flat[i], 0
-            if ws > 1:
-                flat.div_(ws)
-            for p in bucket:
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
-        self._handles = []
+            for p, slot in self._slots(i):
+                if self._is_view(p, slot):
+                    continue
+                if self.overlap:
+                    p.grad = slot.view_as(p)      # re-establish the view a zero_grad(set_to_none=True) dropped
+                else:
+                    if p.grad is None:
+                        p.grad = torch.empty_like(p)
+                    p.grad.copy_(slot.view_as(p))
+            self._handles[i], self._launched[i], self._ready[i] = None, False, 0
+
+    def launched(self):
+        """how many buckets are already in flight (overlap mode: counted after backward, before reduce())"""
+        return sum(self._launched)
 
     def nbytes(self):
         return 4 * sum(p.numel() for p in self.params)

@@ -72,7 +72,21 @@ def _worker(rank, world_size, port, ret):
         buckets = parallel.GradientBuckets(net.parameters(), bucket_mb=0.0005)   # tiny buckets: several per model
         buckets.reduce().wait()
         ok_grad = len(buckets.buckets) > 1 and all(torch.allclose(p.grad, r, rtol=1e-5, atol=1e-6) for p, r in zip(net.parameters(), ref))
-        ret[rank] = (ok_data, ok_grad)
+        # overlap mode: gradients are views into the buckets, hooks launch a bucket's all-reduce during backward
+        torch.manual_seed(0)
+        net2 = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 3, 3, padding=1))
+        net2.load_state_dict(net.state_dict())
+        ov = parallel.GradientBuckets(net2.parameters(), bucket_mb=0.0005, overlap=True)
+        ok_overlap = True
+        for it in range(2):                       # the second pass checks that the state resets and the views survive
+            net2.zero_grad(set_to_none=False)
+            ((net2(xs) - ys) ** 2).mean().backward()
+            in_flight = ov.launched()
+            ov.reduce().wait()
+            ok_overlap &= in_flight >= len(ov.buckets) - 1      # every bucket completed by backward was launched by its hook
+            ok_overlap &= all(torch.allclose(p.grad, r, rtol=1e-5, atol=1e-6) for p, r in zip(net2.parameters(), ref))
+            ok_overlap &= all(any(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + 4 * f.numel() for f in ov._flat) for p in net2.parameters())
+        ret[rank] = (ok_data, ok_grad and ok_overlap)
     finally:
         dist.destroy_process_group()
 
