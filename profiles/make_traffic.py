@@ -21,8 +21,8 @@ ROWS = [  # (label, raw file, kernel-name substring, algorithmic bytes per launc
     ("gemm_f32_fwd (C2, 16 pairs)", "c2", "gemm_f32_kernel<128, 128, 2, 2, false, false", 16 * (C2_PAIR + 2 * HAT)),
     ("gemm_f32_bwd_d_a (C2)", "c2", "gemm_f32_kernel<256, 128, 4, 2, true, true", 16 * (C2_PAIR + 2 * HAT)),
     ("gemm_f32_bwd_d_r (C2)", "c2", "gemm_f32_kernel<256, 128, 4, 2, true, false", 16 * (C2_PAIR + 2 * HAT)),
-    ("corr_normalise (one of two launches)", "c2", "corr_normalise_kernel", 16 * 2 * HAT),
-    ("corr_normalise_bwd", "c2", "corr_normalise_bwd_kernel", 16 * 3 * HAT),
+    ("corr_normalise (one of two launches)", "c2", "corr_normalise_keep_kernel", 16 * 2 * HAT),
+    ("corr_normalise_bwd", "c2", "corr_normalise_bwd_keep_kernel", 16 * 3 * HAT),
     ("warp_fwd align_set 256^2 x128 (C3)", "ops", "warp_fwd_kernel<false, true, 1, true>", NPIX_C3 * 40),
     ("warp_bwd grad-grid 256^2 x128 (C3)", "ops", "warp_bwd_kernel<false, false, true, true>", NPIX_C3 * 40),
     ("warp_bwd grad-grid + grad-input", "ops", "warp_bwd_kernel<false, true, true, true>", NPIX_C3 * 52),
