@@ -575,6 +575,38 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
   // The tiles were accumulated transposed (B fragment as the MFMA's A operand): a lane holds ONE row m of D and, in
   // each register quad, four consecutive columns n -> one 16-byte store per quad instead of four 4-byte stores.
   float *Db = g.D + (int64_t)z * g.d_bs;
+#ifndef TCL_GEMM_DIRECT_EPI   // A/B switch: the direct epilogue below for every case
+  if (FULL && EPI == EPI_STORE && TM == 2 && TN == 2 && WM == 2 && WN == 2 && g.d_vec) {
+    // Full tiles: the accumulators go through LDS once so that every store instruction of a wave writes eight complete,
+    // line-aligned 128-byte row segments (the direct path writes 32-byte pieces of 32 different rows per instruction), and
+    // those leave as non-temporal stores (whole lines: nothing to merge in L2, and the operand panels stay there).
+    // One pass per (i, j): 64 rows x (2 x 32) columns = 16 KB, rows padded to 68 floats.  C2 forward: 1.205 -> 1.188 ms
+    // back to back (non-temporal stores of the direct path's 16-byte pieces had doubled the time of the bf16 variant).
+    constexpr int ELD = 68;
+    static_assert(64 * ELD <= A_LDS + B_LDS, "epilogue staging must fit the operand buffers");
+    const int wm = wid / WN, wn = wid % WN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (i + j > 0) __syncthreads();   // the previous pass has been read back (the k-loop itself ended on a barrier)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 val = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          *reinterpret_cast<f32x4 *>(smem + (wm * 32 + lr) * ELD + wn * 32 + 8 * q + 4 * lh) = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int idx = tid + NT * k, row = idx >> 4, c4 = idx & 15, seg = c4 >> 3, within = (c4 & 7) * 4;
+          const f32x4 val = *reinterpret_cast<const f32x4 *>(smem + row * ELD + seg * 32 + within);
+          const int m = m0 + (row >> 5) * (BM / WM) + i * 32 + (row & 31), n = n0 + seg * (BN / WN) + j * 32 + within;
+          __builtin_nontemporal_store(val, reinterpret_cast<f32x4 *>(Db + (int64_t)m * g.d_ld + n));
+        }
+      }
+    return;
+  }
+#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -800,6 +832,36 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
   // The tiles were accumulated transposed (B fragment as the MFMA's A operand): a lane holds ONE row m of D and, in
   // each register quad, four consecutive columns n -> one 16-byte store per quad instead of four 4-byte stores.
   float *Db = g.D + (int64_t)z * g.d_bs;
+#ifndef TCL_GEMM_DIRECT_EPI
+  if (TM == 2 && TN == 2 && WM == 2 && WN == 2 && g.d_vec && m0 + BM <= g.M && n0 + BN <= g.N) {   // block-uniform
+    // full tile: LDS-transposed epilogue with whole-line non-temporal stores, as in gemm_f32_kernel (this variant is bound by
+    // the volume store)
+    constexpr int ELD = 68;
+    static_assert(64 * ELD * 4 <= NS * (A_IMG + B_IMG) * 2, "epilogue staging must fit the operand images");
+    float *stage = reinterpret_cast<float *>(smem);
+    const int wm = wid / WN, wn = wid % WN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (i + j > 0) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 val = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          *reinterpret_cast<f32x4 *>(stage + (wm * 32 + lr) * ELD + wn * 32 + 8 * q + 4 * lh) = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int idx = tid + NT * k, row = idx >> 4, c4 = idx & 15, seg = c4 >> 3, within = (c4 & 7) * 4;
+          const f32x4 val = *reinterpret_cast<const f32x4 *>(stage + row * ELD + seg * 32 + within);
+          const int m = m0 + (row >> 5) * (BM / WM) + i * 32 + (row & 31), n = n0 + seg * (BN / WN) + j * 32 + within;
+          __builtin_nontemporal_store(val, reinterpret_cast<f32x4 *>(Db + (int64_t)m * g.d_ld + n));
+        }
+      }
+    return;
+  }
+#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
