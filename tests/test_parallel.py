@@ -135,3 +135,27 @@ def test_c4_network_matches_the_reference_parameter_count():
     net = harness_c4.CopyPasteNet()
     assert sum(p.numel() for p in net.parameters()) == 21631385
     assert sum(p.numel() for n, p in net.named_parameters() if "conv6" in n) == 4719616
+
+
+def test_gradient_buckets_overlap_survives_dropped_views():
+    """overlap mode, single process: zero_grad(set_to_none=True) drops the bucket views; the next cycle packs the fresh gradients,
+    hands back views again, and a parameter that took no part in backward counts as zeros."""
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 2))
+    unused = torch.nn.Parameter(torch.ones(3))
+    params = list(net.parameters()) + [unused]
+    gb = parallel.GradientBuckets(params, bucket_mb=0.0001, overlap=True)
+    x = torch.randn(4, 5)
+    for mode in (False, True, True):
+        for p in params:
+            if mode:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+        ref = torch.autograd.grad(net(x).pow(2).sum(), list(net.parameters()))
+        net(x).pow(2).sum().backward()
+        gb.reduce().wait()
+        for p, r in zip(net.parameters(), ref):
+            assert torch.allclose(p.grad, r, rtol=1e-6, atol=1e-7)
+        assert torch.equal(unused.grad, torch.zeros(3))
+        assert all(any(f.data_ptr() <= p.grad.data_ptr() < f.data_ptr() + 4 * f.numel() for f in gb._flat) for p in params)
