@@ -199,7 +199,9 @@ int tcl_dilate_cross3(const float *img, float *out, int64_t N, int64_t H, int64_
 /* ---------------------------------------------------------------------------------------------
  * A10-A13  flow utilities, utils/flow.py.
  * ------------------------------------------------------------------------------------------- */
-/* corr_to_flow, utils/flow.py:8-26: corr (N,S*S [target], S*S [ref]) -> flow (N,S*S,2); first-max tie-break. */
+/* corr_to_flow, utils/flow.py:8-26: corr (N,S*S [target], S*S [ref]) -> flow (N,S*S,2); first-max tie-break.
+ *   NaN similarities are UNSUPPORTED here and in tcl_corr4d_argmax_flow: torch.argmax treats NaN as the maximum, these
+ *   kernels compare with `>` and skip NaN entries (a row of finite values is bit-exact with the reference). */
 int tcl_corr_to_flow(const float *corr, float *flow, int64_t N, int64_t S, void *stream);
 /* flow_abs_to_relative (sign=-1) / flow_relative_to_abs (sign=+1), utils/flow.py:29-66.  flow (N,H,W,2). */
 int tcl_flow_add_identity(const float *flow, float *out, int64_t N, int64_t H, int64_t W, int sign, void *stream);

@@ -21,6 +21,25 @@ from ._lib import LIB_PATH, TclError, lib  # noqa: F401
 __version__ = "0.1.0"
 
 
+# functions the reference's DataLoader workers call on CPU tensors (thesis/dataset.py:281-289: crop_flow / resize_flow on
+# the flows of utils/movement.py, in forked worker processes that must never touch the GPU)
+_CPU_ROUTED = ("crop_flow", "resize_flow", "flow_abs_to_relative", "flow_relative_to_abs")
+
+
+def _route_cpu_to(original, ours):
+    """The drop-in for a function the reference also calls on CPU tensors: GPU tensors go to the HIP op, CPU tensors to the
+    function that was replaced (the reference's own code, untouched).  This package has no CPU arithmetic of its own."""
+    import functools
+
+    @functools.wraps(ours)
+    def routed(flow, *args, **kwargs):
+        if getattr(flow, "is_cuda", False):
+            return ours(flow, *args, **kwargs)
+        return original(flow, *args, **kwargs)
+    routed.__tcl_original__ = original
+    return routed
+
+
 def install_dropin(reference_modules=None):
     """Patch the reference's hot-path symbols in place with this package's implementations.
 
@@ -28,6 +47,11 @@ def install_dropin(reference_modules=None):
         {'utils.correlation': mod, 'utils.flow': mod, 'models.cpn': mod, 'models.cpn_original': mod};
     by default they are looked up in sys.modules.  Only functions/classes on the hot path are replaced; the conv
     stacks, runners and data code of the reference stay untouched.
+
+    CPU tensors: the reference's dataset code calls `crop_flow` / `resize_flow` (and through them the abs<->rel helpers) on
+    CPU tensors inside DataLoader workers.  For those four functions the installed symbol keeps a handle to the function it
+    replaces and hands CPU tensors to it, so the data pipeline runs as before; GPU tensors take the HIP kernels.  Every
+    other op has no CPU route and raises TclError on a CPU tensor.
     """
     import sys
 
@@ -49,7 +73,13 @@ def install_dropin(reference_modules=None):
         if target is None:
             continue
         for sym in symbols:
-            setattr(target, sym, getattr(src, sym))
+            ours = getattr(src, sym)
+            if sym in _CPU_ROUTED:
+                original = getattr(target, sym, None)
+                original = getattr(original, "__tcl_original__", original)      # installing twice keeps the first original
+                if callable(original) and original is not ours:
+                    ours = _route_cpu_to(original, ours)
+            setattr(target, sym, ours)
             patched.append("%s.%s" % (name, sym))
     # CPNet keeps its own conv stacks and weights; its two hot methods are rebound so that the affine warp and (through the
     # patched CPNContextMatchingDefault of new instances) the context matching run on the HIP kernels

@@ -11,6 +11,12 @@ import torch
 from . import _lib
 from ._lib import TclError
 
+# Under torch.autocast the surrounding convolutions hand the ops bf16 / fp16 tensors.  The kernels compute in fp32, so every
+# autograd Function casts its floating-point GPU inputs to fp32 at the op boundary while autocast is active (and runs its
+# body with autocast off), exactly as a stock fp32-only op behaves; outside autocast a non-fp32 tensor is an error.
+_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 
 # ----------------------------------------------------------------------------------------------- helpers
 def _require_device(*tensors):
@@ -51,6 +57,7 @@ def _planes(t, h, w):
 # ----------------------------------------------------------------------------------------------- A1 corr4d
 class Corr4dFn(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, x_t, v_t, x_r, v_r, precision):
         dev = _require_device(x_t, v_t, x_r, v_r)
         b, c, f, h, w = x_r.shape
@@ -71,6 +78,7 @@ class Corr4dFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         xt, vt, xr, vr, ws = ctx.saved_tensors
         b, c, f, h, w, precision = ctx.dims
@@ -89,8 +97,17 @@ class Corr4dFn(torch.autograd.Function):
         return g_t, None, g_r, None, None
 
 
-def corr4d(x_t, v_t, x_r, v_r, precision=_lib.PREC_F32):
-    return Corr4dFn.apply(x_t, v_t, x_r, v_r, precision)
+def corr4d(x_t, v_t, x_r, v_r, precision=None):
+    """precision None: selected by the input dtype: fp32 tensors -> exact fp32 MFMA; bf16 / fp16 tensors ("bf16 is
+    a build extension selected by input dtype") -> the bf16-MFMA variant with fp32 accumulation, result in the input dtype
+    (what torch.matmul of the reference returns for such inputs)."""
+    low = x_r.dtype in (torch.bfloat16, torch.float16) and not torch.is_autocast_enabled("cuda")
+    if low:
+        in_dtype = x_r.dtype
+        f32 = lambda t: None if t is None else t.float()
+        out = Corr4dFn.apply(f32(x_t), f32(v_t), f32(x_r), f32(v_r), _lib.PREC_BF16 if precision is None else precision)
+        return out.to(in_dtype)
+    return Corr4dFn.apply(x_t, v_t, x_r, v_r, _lib.PREC_F32 if precision is None else precision)
 
 
 def corr4d_argmax_flow(x_t, v_t, x_r, v_r):
@@ -113,6 +130,7 @@ def corr4d_argmax_flow(x_t, v_t, x_r, v_r):
 # ----------------------------------------------------------------------------------------------- A2 corr1x1
 class Corr1x1Fn(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, f1, f2, m1, m2):
         dev = _require_device(f1, f2, m1, m2)
         b, c, h, w = f1.shape
@@ -125,6 +143,7 @@ class Corr1x1Fn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         f1, f2, m1, m2 = ctx.saved_tensors
         b, c, h, w = f1.shape
@@ -144,6 +163,7 @@ class WarpFn(torch.autograd.Function):
     v_out likewise.  Gradients flow to x and to the grid / theta; v is data."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, v, grid, theta, align_corners, v_mode):
         dev = _require_device(x, v, grid, theta)
         b, c, f, h, w = x.shape
@@ -172,6 +192,7 @@ class WarpFn(torch.autograd.Function):
         return x_out.transpose(1, 2), v_ret
 
     @staticmethod
+    @_bwd
     def backward(ctx, g_x_out, _g_v_out):
         xs, gridc, thetac = ctx.saved_tensors
         b, c, f, h, w = ctx.x_shape
@@ -198,6 +219,7 @@ class AffineGridFn(torch.autograd.Function):
     """theta (N,2,3) -> grid (N,H,W,2) = F.affine_grid(theta, (N,*,H,W), align_corners)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, theta, h, w, align_corners):
         dev = _require_device(theta)
         n = theta.shape[0]
@@ -211,6 +233,7 @@ class AffineGridFn(torch.autograd.Function):
         return grid
 
     @staticmethod
+    @_bwd
     def backward(ctx, g):
         # grid = base @ theta^T with a constant base grid: a (6 x HW) reduction per image; data-side op, torch suffices
         h, w, ac = ctx.meta
@@ -259,6 +282,7 @@ def _softmax_layout(vec, mask, dim):
 
 class MaskedSoftmaxFn(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, vec, mask, dim):
         dev = _require_device(vec)
         if not mask.is_cuda:
@@ -273,6 +297,7 @@ class MaskedSoftmaxFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         vc, maskc = ctx.saved_tensors
         o, om, r, i = ctx.layout
@@ -289,6 +314,7 @@ class ContextMatchingFn(torch.autograd.Function):
     """c_feats (B,C,R+1,h,w), v_t (B,1,H,W), v_aligned (B,1,R,H,W) -> p_in, c_mask (B,1,h,w), c_match (B,R,h,w)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, c_feats, v_t, v_aligned, normalize, variant):
         dev = _require_device(c_feats, v_t, v_aligned)
         b, c, f, h, w = c_feats.shape
@@ -313,6 +339,7 @@ class ContextMatchingFn(torch.autograd.Function):
         return p_in, c_mask, c_match
 
     @staticmethod
+    @_bwd
     def backward(ctx, g_p_in, g_c_mask, _g_c_match):
         cf, c_match, ws = ctx.saved_tensors
         b, c, r, h, w, variant, normalize = ctx.meta
@@ -379,6 +406,7 @@ def corr_to_flow(corr):
 
 class FlowAddIdentityFn(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, flow, sign):
         dev = _require_device(flow)
         b, f, h, w, two = flow.shape
@@ -389,12 +417,14 @@ class FlowAddIdentityFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd
     def backward(ctx, g):
         return g, None
 
 
 class CropFlowFn(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, flow, crop_size, crop_position):
         dev = _require_device(flow)
         b, f, h, w, two = flow.shape
@@ -408,6 +438,7 @@ class CropFlowFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd
     def backward(ctx, g):
         b, f, h, w, ch, cw, py, px = ctx.meta
         gf = g.new_zeros((b, f, h, w, 2))
@@ -418,6 +449,7 @@ class CropFlowFn(torch.autograd.Function):
 
 class ResizeFlowFn(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, flow, size):
         dev = _require_device(flow)
         b, f, h, w, two = flow.shape
@@ -430,6 +462,7 @@ class ResizeFlowFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd
     def backward(ctx, g):
         # gradient of a nearest gather: scatter-add back (flows of the hot path are data here; torch ops suffice)
         b, f, h, w, oh, ow = ctx.meta

@@ -1054,7 +1054,11 @@ static bool norm_vec_ok(int64_t P, const void *a, const void *b, const void *c, 
   return P % 4 == 0 && aligned(a, 16) && aligned(b, 16) && aligned(c, 16) && aligned(d, 16) && aligned(e, 16);
 }
 static void launch_normalise(hipStream_t s, const float *x, const float *v, float *hat, float *nrm, int64_t BF, int C, int F, int64_t P) {
-  static const bool keep = getenv("TCL_NORM_NO_KEEP") == nullptr;   // A/B switch
+#ifdef TCL_NORM_NO_KEEP   // A/B switch of side builds (-DTCL_NORM_NO_KEEP): the two-loop kernels everywhere
+  const bool keep = false;
+#else
+  const bool keep = true;
+#endif
   const bool vec = norm_vec_ok(P, x, v, hat, nrm, nullptr);
 #define TCL_NORM_KEEP(NCG) hipLaunchKernelGGL((corr_normalise_keep_kernel<2, NCG, 16>), dim3((unsigned)cdiv(P, 128), (unsigned)BF), dim3(64 * NCG), 0, s, x, v, hat, nrm, C, F, (int)P)
   if (vec && keep && C <= 256) {   // single read of x: the thread's <= 16 channels stay in registers
@@ -1072,7 +1076,11 @@ static void launch_normalise(hipStream_t s, const float *x, const float *v, floa
 }
 static void launch_normalise_bwd(hipStream_t s, const float *x, const float *v, const float *dhat, const float *nrm, float *gx, int64_t BF,
                                  int C, int F, int64_t P) {
-  static const bool keep = getenv("TCL_NORM_NO_KEEP") == nullptr;
+#ifdef TCL_NORM_NO_KEEP
+  const bool keep = false;
+#else
+  const bool keep = true;
+#endif
   const bool vec = norm_vec_ok(P, x, v, dhat, nrm, gx);
 #define TCL_NORM_KEEP(NCG) hipLaunchKernelGGL((corr_normalise_bwd_keep_kernel<2, NCG, 16>), dim3((unsigned)cdiv(P, 128), (unsigned)BF), dim3(64 * NCG), 0, s, x, v, dhat, nrm, gx, C, F, (int)P)
   if (vec && keep && C <= 256) {   // x and d_hat read once; two pixels per lane so that 2 x 16 channels fit the register budget

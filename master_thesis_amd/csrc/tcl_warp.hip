@@ -385,11 +385,12 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
   TCL_REQUIRE((x_out == nullptr) || (x != nullptr && C > 0), TCL_ERR_ARG, "tcl_warp_fwd: x_out given without x");
   TCL_REQUIRE(x_out || v_mode != TCL_VMODE_NONE, TCL_ERR_ARG, "tcl_warp_fwd: nothing to compute");
   TCL_REQUIRE(!grid || aligned(grid, 8), TCL_ERR_ARG, "tcl_warp_fwd: grid must be 8-byte aligned");
-  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536 && cdiv(H * W, 256) * NF < 65536, TCL_ERR_SHAPE,
+  // frames per XCD unit: NF only when every frame of a batch item samples ONE shared source frame (frame stride 0)
+  const int64_t gf = (x_out && x_sf == 0 && (!v || v_sf == 0)) ? NF : 1;
+  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536 && cdiv(H * W, 256) * gf < 65536, TCL_ERR_SHAPE,
               "tcl_warp_fwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   WarpArgs a{x, x_sb, x_sf, x_sc, v, v_sb, v_sf, grid, theta, x_out, xo_sb, xo_sf, xo_sc, v_out, vo_sb, vo_sf,
-             (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H),
-             (x_out && x_sf == 0 && (!v || v_sf == 0)) ? (int)NF : 1};
+             (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H), (int)gf};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grd = warp_grid(cdiv(H * W, 256), a.gf, NB * NF), blk(256);
   const bool c3 = x_out != nullptr && C == 3;

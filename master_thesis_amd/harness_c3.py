@@ -12,7 +12,7 @@ the share of the hot path in a real step can be measured:
                        estimators, on stock torch convolutions, state_dict-compatible); bf16 autocast for the convolutions in
                        C3, the volume and the warps stay fp32
   after the network -> `runners.train_step_propagate`: six `align_set` warps at 16 / 64 / 256 px, two `resize_flow`s, `v_map`s
-  loss              -> `alignment_loss`: the terms of ThesisAlignmentRunner.compute_loss (thesis_dfpn/runner.py:161-206)
+  loss              -> `runners.ThesisAlignmentRunner.compute_loss` (thesis_dfpn/runner.py:162-206, reference signature)
 
 Run:  python -m master_thesis_amd.harness_c3 --sequences 32 --bf16          (C3, 1 GPU: 128 pairs per step)
       python -m master_thesis_amd.harness_c3 --sequences 1 --forward-only    (C1's shape on the GPU)
@@ -29,7 +29,6 @@ import torch.nn.functional as F
 
 from . import runners
 from .models import thesis_alignment
-from .utils import correlation
 from .utils.losses import LossesUtils
 
 
@@ -67,26 +66,6 @@ def AlignmentNet(features):
     """The drop-in network (models.thesis_alignment.ThesisAlignmentModel of this package, pinned against the reference's
     forward by tests/golden/alignment_model.npz) around the given feature extractor."""
     return thesis_alignment.ThesisAlignmentModel(features)
-
-
-def alignment_loss(features, losses, corr, xs, vs, ys, xs_aligned, flows, flows_gt, flows_use, t, r_list):
-    """Correlation L1 against the volume of the ground-truth frames, three flow L1 terms, two masked reconstruction terms.
-    thesis_dfpn/runner.py:161-206."""
-    b, c, f, h, w = ys[2].size()
-    with torch.no_grad():
-        y_in = ys[2].transpose(1, 2).reshape(b * f, c, h, w)
-        if (h, w) != (256, 256):
-            y_in = F.interpolate(y_in, (256, 256), mode='bilinear')
-        y_feats = features(y_in)[3].float().reshape(b, f, -1, 16, 16).transpose(1, 2)
-        corr_y = correlation.compute_masked_4d_correlation(y_feats[:, :, t], None, y_feats[:, :, r_list], None)
-    items = [F.l1_loss(corr.float(), corr_y)]
-    for k in range(3):
-        items.append(losses.masked_l1(flows[k].float(), flows_gt[k], torch.ones_like(flows_gt[k]), flows_use))
-    for k in (1, 2):
-        outside = ((flows[k] < -1).float() + (flows[k] > 1).float()).sum(4).clamp(0, 1).unsqueeze(1)
-        target = xs[k][:, :, t].unsqueeze(2).expand_as(xs_aligned[k])
-        items.append(losses.masked_l1(target, xs_aligned[k], vs[k][:, :, t].unsqueeze(2) * (1 - outside), reduction='sum'))
-    return sum(items), items
 
 
 def main():
@@ -133,7 +112,7 @@ def main():
         if args.forward_only:
             return out[0].float().mean()
         corr, xs, vs, ys, xs_al, _, _, _, flows, flows_gt, use, _, _ = out
-        loss, _ = alignment_loss(features, losses, corr, xs, vs, ys, xs_al, flows, flows_gt, use, t, r_list)
+        loss, _ = runners.ThesisAlignmentRunner.compute_loss(features, losses, corr, xs, vs, ys, xs_al, flows, flows_gt, use, t, r_list)
         opt.zero_grad(set_to_none=False)
         loss.backward()
         buckets.reduce().wait()

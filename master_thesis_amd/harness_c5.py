@@ -7,8 +7,9 @@ Only the hot path is this package's product; the rest of the step exists here so
   inpainting net   -> `InpaintingNet`: the architecture of ThesisInpaintingVisible / RRDBNet(in=9, out=3, nb=20, nf=64, gc=32)
                       (models/thesis_inpainting.py:6-36, models/rrdb_net.py:14-76) restated on stock torch convolutions
                       (MIOpen); 14,690,883 parameters = 58.76 MB of fp32 gradients, as SURVEY.md §8d records
-  loss             -> the three masked-L1 terms of ThesisInpaintingRunner.compute_loss (thesis_inpainting/runner.py:114-128);
-                      the perceptual term needs pretrained VGG weights that are not available offline and is left out
+  loss             -> all five terms of ThesisInpaintingRunner.compute_loss (thesis_inpainting/runner.py:114-128) through
+                      `runners.ThesisInpaintingRunner.compute_loss`; the perceptual term runs on a seeded stand-in extractor of
+                      VGG-16's layout (pretrained weights are not available offline)
   gradient exchange-> `parallel.GradientBuckets`: the one collective of the whole system (RCCL all-reduce over xGMI)
 
 Run:  python -m master_thesis_amd.harness_c5 --sequences 8            (1 GPU)
@@ -78,26 +79,42 @@ class InpaintingNet(nn.Module):
         return y_hat, v_target * x_target + (1 - v_target) * y_hat
 
 
-def masked_l1(inp, target, mask, weight):
-    """utils/losses.py:26-32 with reduction='sum'."""
-    return weight * F.l1_loss(inp * mask, target * mask, reduction='sum') / (torch.sum(mask) + 1e-9)
+class PerceptualStandIn(nn.Module):
+    """Five feature levels at strides 2..32 with VGG-16's widths (the interface of models/vgg_16.py:18-27: a list of the five
+    max-pool outputs).  The reference's perceptual term uses pretrained VGG-16 weights, which cannot be fetched here; a seeded,
+    frozen stack of the same layout keeps the term (and its share of the step) in place."""
+
+    def __init__(self):
+        super().__init__()
+        widths, c = (64, 128, 256, 512, 512), 3
+        self.levels = nn.ModuleList()
+        for wd in widths:
+            self.levels.append(nn.Sequential(nn.Conv2d(c, wd, 3, stride=2, padding=1), nn.ReLU()))
+            c = wd
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, x, normalize_input=False):
+        out = []
+        for level in self.levels:
+            x = level(x)
+            out.append(x)
+        return out
 
 
-def compute_loss(y_target, v_target, y_hat, y_hat_comp, v_map):
-    """The masked-L1 terms of thesis_inpainting/runner.py:114-128 (non-hole 0.5, visible hole 2, non-visible hole 1)."""
-    f = y_hat.size(2)
-    target = y_target.unsqueeze(2).repeat(1, 1, f, 1, 1)
-    nh = v_target.unsqueeze(2).repeat(1, 1, f, 1, 1)
-    nvh = (1 - nh) - v_map
-    return masked_l1(y_hat, target, nh, 0.5) + masked_l1(y_hat, target, v_map, 2.0) + masked_l1(y_hat_comp, target, nvh, 1.0)
+def compute_loss(utils_losses, y_target, v_target, y_hat, y_hat_comp, v_map):
+    """All five terms of thesis_inpainting/runner.py:114-128 (non-hole 0.5, visible hole 2, non-visible hole 1, perceptual 0.5,
+    Sobel gradient 1) through the drop-in static function."""
+    from . import runners
+    return runners.ThesisInpaintingRunner.compute_loss(utils_losses, y_target, v_target, y_hat, y_hat_comp, v_map)[0]
 
 
-def train_step(aligner, net, buckets, optimizer, x, m, y, t, r_list):
+def train_step(aligner, net, buckets, optimizer, x, m, y, t, r_list, utils_losses):
     """One data-parallel step on this rank's shard: frozen aligner (hot path) -> net -> loss -> bucketed all-reduce -> Adam."""
     from . import runners
     x_al, v_al, v_map = runners.infer_step_propagate(aligner, x[:, :, t], m[:, :, t], x[:, :, r_list], m[:, :, r_list])
     y_hat, y_hat_comp = net(x[:, :, t], 1 - m[:, :, t], x_al, v_al, v_map)
-    loss = compute_loss(y[:, :, t], 1 - m[:, :, t], y_hat, y_hat_comp, v_map)
+    loss = compute_loss(utils_losses, y[:, :, t], 1 - m[:, :, t], y_hat, y_hat_comp, v_map)
     optimizer.zero_grad(set_to_none=False)
     loss.backward()
     buckets.reduce().wait()
@@ -136,6 +153,8 @@ def main():
 
     torch.manual_seed(0)
     net = InpaintingNet(nb=args.nb).to(dev)
+    from .utils.losses import LossesUtils
+    utils_losses = LossesUtils(PerceptualStandIn().to(dev), dev)
     buckets = parallel.GradientBuckets(net.parameters(), overlap=True)   # all-reduce of a bucket starts under the rest of backward
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     t, r_list = 1, [0]
@@ -143,7 +162,7 @@ def main():
     def step():
         for i in range(0, n, args.micro_batch):
             sl = slice(i, min(i + args.micro_batch, n))
-            loss = train_step(aligner, net, buckets, opt, x[sl], m[sl], y[sl], t, r_list)
+            loss = train_step(aligner, net, buckets, opt, x[sl], m[sl], y[sl], t, r_list, utils_losses)
         return loss
 
     step()

@@ -72,7 +72,8 @@ class GradientBuckets:
     overlap=True (built BEFORE backward): every `p.grad` becomes a view into its bucket (no pack / unpack copies) and a
         post-accumulate hook launches a bucket's all-reduce the moment its last gradient has been accumulated, so the
         collectives run under the rest of backward; `reduce()` then only launches buckets that backward did not complete
-        (parameters without a gradient count as zeros) and `wait()` only waits.  One backward per reduce()/wait() cycle;
+        (parameters without a gradient count as zeros) and `wait()` only waits.  Buckets are launched strictly in index
+        order on every rank, whatever order the hooks fire in.  One backward per reduce()/wait() cycle;
         use `zero_grad(set_to_none=False)` so that the views survive (a replaced gradient is copied in and out instead)."""
 
     def __init__(self, params, bucket_mb=25.0, overlap=False):
@@ -92,6 +93,7 @@ class GradientBuckets:
         self._handles = [None] * nb
         self._launched = [False] * nb
         self._ready = [0] * nb
+        self._next = 0          # first bucket not yet launched in this cycle: launches happen in index order only
         self.overlap = bool(overlap)
         self._hooks = []
         if self.overlap:
@@ -127,9 +129,15 @@ class GradientBuckets:
 
     # -- launching
     def _on_grad(self, i):
+        # Collectives are matched across ranks purely by ISSUE ORDER, so buckets are launched strictly in bucket-index order
+        # (as DDP does): a bucket that completes early waits until every bucket before it has been launched.  A rank whose
+        # graph leaves a parameter without a gradient simply stops launching from hooks at that bucket; reduce() flushes the
+        # rest in the same order, so every rank issues bucket 0, 1, 2, ... whatever its graph looked like.
         self._ready[i] += 1
-        if self._ready[i] == len(self.buckets[i]) and not self._launched[i]:
-            self._launch(i)
+        assert self._ready[i] <= len(self.buckets[i]), \
+            "bucket %d saw more gradient accumulations than parameters: one backward per reduce()/wait() cycle" % i
+        while self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next]):
+            self._launch(self._next)
 
     def _launch(self, i):
         rank, ws = world()
@@ -144,11 +152,11 @@ class GradientBuckets:
             flat.div_(ws)
             self._handles[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         self._launched[i] = True
+        self._next = i + 1
 
     def reduce(self):
-        for i in range(len(self.buckets)):
-            if not self._launched[i]:
-                self._launch(i)
+        for i in range(self._next, len(self.buckets)):
+            self._launch(i)
         return self
 
     def wait(self):
@@ -165,6 +173,7 @@ class GradientBuckets:
                         p.grad = torch.empty_like(p)
                     p.grad.copy_(slot.view_as(p))
             self._handles[i], self._launched[i], self._ready[i] = None, False, 0
+        self._next = 0
 
     def launched(self):
         """how many buckets are already in flight (overlap mode: counted after backward, before reduce())"""

@@ -70,10 +70,44 @@ def infer_step_propagate(model, x_target, m_target, x_ref, m_ref):
     return x_ref_aligned, v_ref_aligned, v_map
 
 
+def compute_loss(model_vgg, utils_losses, corr, xs, vs, ys, xs_aligned, flows, flows_gt, flows_use, t, r_list):
+    """thesis_dfpn/runner.py:162-206, same arguments and return value `(total_loss, [corr_loss, flow_loss_16, flow_loss_64,
+    flow_loss_256, alignment_recons_64, alignment_recons_256])`.
+
+    The second call site of the cost volume (thesis_dfpn/runner.py:175): the volume of the ground-truth frames' features,
+    masks None, under no_grad, is the target of an L1 term on the predicted volume.  `model_vgg(images) -> list` whose [3] is
+    the (N,512,16,16) level; `utils_losses.masked_l1` as in utils/losses.py:26-32."""
+    from .utils import correlation
+    b, c, f, h, w = ys[2].size()
+    n_ref = len(r_list)
+    with torch.no_grad():
+        y_in = ys[2].transpose(1, 2).reshape(b * f, c, h, w)
+        if (h, w) != (256, 256):
+            y_in = F.interpolate(y_in, (256, 256), mode='bilinear')
+        y_feats = model_vgg(y_in)[3].float().reshape(b, f, -1, 16, 16).transpose(1, 2)
+        corr_y = correlation.compute_masked_4d_correlation(y_feats[:, :, t], None, y_feats[:, :, r_list], None)
+    corr_loss = F.l1_loss(corr.float(), corr_y)
+
+    flow_losses = [utils_losses.masked_l1(flows[k].float(), flows_gt[k], torch.ones_like(flows_gt[k]), flows_use) for k in range(3)]
+
+    recons = []
+    for k in (1, 2):   # 64 and 256 px: target frame against each aligned reference, inside the target's visible area and the frame
+        outside = ((flows[k] < -1).float() + (flows[k] > 1).float()).sum(4).clamp(0, 1).unsqueeze(1)
+        target = xs[k][:, :, t].unsqueeze(2).expand(-1, -1, n_ref, -1, -1)
+        visible = vs[k][:, :, t].unsqueeze(2).expand(-1, -1, n_ref, -1, -1) * (1 - outside)
+        recons.append(utils_losses.masked_l1(target, xs_aligned[k], visible, reduction='sum'))
+
+    items = [corr_loss] + flow_losses + recons
+    total_loss = corr_loss + flow_losses[0] + flow_losses[1] + flow_losses[2]
+    total_loss = total_loss + recons[0] + recons[1]
+    return total_loss, items
+
+
 class ThesisAlignmentRunner:
-    """Namespace with the reference class's static step functions (thesis_dfpn/runner.py:104-159)."""
+    """Namespace with the reference class's static step functions (thesis_dfpn/runner.py:104-206)."""
     train_step_propagate = staticmethod(train_step_propagate)
     infer_step_propagate = staticmethod(infer_step_propagate)
+    compute_loss = staticmethod(compute_loss)
 
 
 class ThesisCPNRunner:

@@ -21,6 +21,27 @@ import numpy as np
 F32 = np.float32
 EPS = F32(1e-9)
 
+# Accumulator of the LONG reductions (the 203,520-term similarity of context matching and the sums of its backward, the
+# per-image theta gradient).  float32 restates the reference's own arithmetic; tests that hold the HIP path to the fp32
+# bar at full size switch to float64 (`with long_sums(np.float64)`), so that the yardstick is the exact sum of the same
+# terms rather than another float32 summation order.
+_ACC = F32
+
+
+class long_sums:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _ACC
+        self.prev, _ACC = _ACC, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _ACC
+        _ACC = self.prev
+        return False
+
 
 def _f(a):
     return np.ascontiguousarray(a, dtype=F32)
@@ -383,7 +404,7 @@ def _context_common(c_feats, v_t, v_aligned, variant, normalize):
     zeros = v_sum < F32(1e-4)
     v_sum = v_sum + zeros.astype(F32)
     ft, fr = cf[:, :, 0], cf[:, :, 1:]
-    gs = np.sum(vmap * ft[:, :, None] * fr, axis=(1, 3, 4), dtype=F32)  # (B,R)
+    gs = np.sum((vmap * ft[:, :, None]).astype(_ACC) * fr.astype(_ACC), axis=(1, 3, 4), dtype=_ACC).astype(F32)  # (B,R)
     if variant == "cm_module":
         norm = v_sum * F32(c)              # cpn_original.py:226 always divides by v_sum and C
     else:
@@ -436,10 +457,10 @@ def context_matching_bwd(c_feats, v_t, v_aligned, grad_p_in, grad_c_mask, normal
     else:
         g_ft_direct, g_out, g_mask = gp[:, :c], gp[:, c:2 * c], gp[:, 2 * c:2 * c + 1] + _f(grad_c_mask)
     g_fr = g_out[:, :, None] * c_match                                    # direct path through c_out
-    d_match = np.sum(g_out[:, :, None] * fr, axis=1, keepdims=True, dtype=F32) - g_mask[:, :, None] * vr
+    d_match = np.sum(g_out[:, :, None].astype(_ACC) * fr.astype(_ACC), axis=1, keepdims=True, dtype=_ACC).astype(F32) - g_mask[:, :, None] * vr
     d_sm = d_match * hole
     d_cos = masked_softmax_bwd(cos, vr, 2, d_sm)                          # (B,1,R,h,w)
-    d_gs = np.sum(d_cos, axis=(1, 3, 4), dtype=F32)                       # (B,R)
+    d_gs = np.sum(d_cos, axis=(1, 3, 4), dtype=_ACC).astype(F32)           # (B,R)
     d_gs = np.where(zeros, F32(0), d_gs / norm).astype(F32)
     coef = d_gs[:, None, :, None, None] * vmap                            # (B,1,R,h,w)
     g_ft = g_ft_direct + np.sum(coef * fr, axis=2, dtype=F32)

@@ -98,3 +98,46 @@ def test_install_dropin_patches_reference_names():
     assert "models.cpn.CPNet.align" in patched and "models.cpn.CPNet.copy_and_paste" in patched
     assert fake["models.cpn"].CPNet.align is m.models.cpn.CPNet.align
     assert fake["models.cpn_original"].CPNOriginal.copy_and_paste is m.models.cpn_original.CPNOriginal.copy_and_paste
+
+
+def test_install_dropin_routes_cpu_tensors_to_the_replaced_original():
+    """thesis/dataset.py:281-289 calls crop_flow / resize_flow on CPU tensors in DataLoader workers: the installed symbols hand
+    CPU tensors to the function they replaced, and keep raising where nothing was replaced."""
+    import types
+    import torch
+    import master_thesis_amd as m
+    calls = []
+    fake = {"utils.flow": types.ModuleType("utils.flow")}
+
+    def original_crop_flow(flow, crop_size, crop_position):
+        calls.append(("crop_flow", tuple(flow.shape), tuple(crop_size), tuple(crop_position)))
+        return "original result"
+
+    def original_resize_flow(flow, size):
+        calls.append(("resize_flow", tuple(flow.shape), tuple(size)))
+        return "original resize"
+
+    fake["utils.flow"].crop_flow = original_crop_flow
+    fake["utils.flow"].resize_flow = original_resize_flow
+    m.install_dropin(fake)
+    cpu_flow = torch.zeros(1, 2, 8, 8, 2)
+    assert fake["utils.flow"].crop_flow(cpu_flow, (4, 4), (1, 2)) == "original result"
+    assert fake["utils.flow"].resize_flow(cpu_flow, (4, 4)) == "original resize"
+    assert calls == [("crop_flow", (1, 2, 8, 8, 2), (4, 4), (1, 2)), ("resize_flow", (1, 2, 8, 8, 2), (4, 4))]
+    # installing again keeps the FIRST original (no wrapper chains)
+    m.install_dropin(fake)
+    assert fake["utils.flow"].crop_flow.__tcl_original__ is original_crop_flow
+    # no original to fall back to (the abs<->rel helpers were absent from the fake module): CPU tensors raise
+    with pytest.raises(m.TclError):
+        fake["utils.flow"].flow_abs_to_relative(cpu_flow)
+    # align_set has no CPU route at all
+    with pytest.raises(m.TclError):
+        fake["utils.flow"].align_set(torch.zeros(1, 3, 1, 4, 4), torch.zeros(1, 1, 1, 4, 4), torch.zeros(1, 1, 4, 4, 2))
+
+
+def test_shipped_library_reads_no_environment_switches():
+    """A/B switches of the kernels are compile-time -D flags of side builds; the shipped sources must not read the environment."""
+    csrc = os.path.join(ROOT, "master_thesis_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, fn)).read(), fn

@@ -265,15 +265,13 @@ def test_cpn_align_c4_shape(mods):
     oxa, ova, _ = O.cpn_align(x, m, None, theta, r_list)
     assert ya is None
     assert_close(N(xa), oxa, what="cpn_align x")
-    got_v = N(va)
-    # bit-exact away from the 0.5 threshold; a sample whose bilinear value sits within fp32 noise of 0.5 may legally flip
-    mism = got_v != ova
-    assert mism.mean() < 1e-5, "v_aligned mismatches: %d" % mism.sum()
+    assert_exact(N(va), ova, what="cpn_align v (bilinear > 0.5)")
     cot = rng.standard_normal(oxa.shape).astype(np.float32)
     gx, gth = torch.autograd.grad((xa * T(cot)).sum(), [tx, tth])
     ogx, ogth = O.cpn_align_bwd(x, theta, r_list, cot)
     assert_close(N(gx), ogx, what="cpn_align g_x")
-    assert_close(N(gth), ogth, rtol=1e-3, atol=1e-3, what="cpn_align g_theta (sum over 101,760 pixels)")
+    # the oracle sums the 101,760 per-pixel terms in float64 (affine_grid_bwd); positions are bit-identical on both sides
+    assert_close(N(gth), ogth, rtol=1e-4, atol=1e-5, what="cpn_align g_theta (sum over 101,760 pixels)")
 
 
 @pytest.mark.parametrize("variant", ["default", "complete", "cm_module"])
@@ -297,7 +295,8 @@ def test_context_matching_c4_shape(mods, variant, normalize):
     else:
         p_in, c_mask = mods["cpo"].CM_Module()(tcf, T(v_t), T(v_al))
         ref_imp = None
-    op, om, oimp = O.context_matching(cf, v_t, v_al, normalize, variant)
+    with O.long_sums(np.float64):      # the 203,520-term similarity sums exactly: the yardstick is not another fp32 order
+        op, om, oimp = O.context_matching(cf, v_t, v_al, normalize, variant)
     assert_close(N(p_in), op, what="p_in")
     assert_close(N(c_mask), om, what="c_mask")
     if ref_imp is not None:
@@ -305,8 +304,9 @@ def test_context_matching_c4_shape(mods, variant, normalize):
     cot1 = rng.standard_normal(op.shape).astype(np.float32)
     cot2 = rng.standard_normal(om.shape).astype(np.float32)
     (g,) = torch.autograd.grad((p_in * T(cot1)).sum() + (c_mask * T(cot2)).sum(), [tcf])
-    og = O.context_matching_bwd(cf, v_t, v_al, cot1, cot2, normalize, variant)
-    assert_close(N(g), og, rtol=1e-3, atol=1e-4, what="g_c_feats (203,520-term sums)")
+    with O.long_sums(np.float64):
+        og = O.context_matching_bwd(cf, v_t, v_al, cot1, cot2, normalize, variant)
+    assert_close(N(g), og, what="g_c_feats (203,520-term sums)")
 
 
 def test_errors_are_loud(mods):
@@ -382,6 +382,22 @@ def test_warp_generic_channel_counts(C, F, H, W):
     assert_close(N(gf), ogf, what="warp g_flow")
 
 
+def test_warp_many_large_frames_one_launch():
+    """200 frames of 300 x 300 = 352 chunks x 200 frames > 65535, each frame with its own source (gf == 1): the
+    forward used to reject what the backward accepts."""
+    from master_thesis_amd import _lib, _ops
+    rng = np.random.default_rng(200)
+    B, C, F, H, W = 1, 1, 200, 300, 300
+    x = rng.random((B, C, F, H, W)).astype(np.float32)
+    v = _masks(rng, (B, 1, F, H, W), 0.7)
+    flow = (rng.random((B, F, H, W, 2)) * 2.2 - 1.1).astype(np.float32)
+    xa, va = _ops.WarpFn.apply(T(x), T(v), T(flow).reshape(-1, H, W, 2), None, True, _lib.VMODE_NEAREST)
+    oxa = O.grid_sample_bilinear(x.transpose(0, 2, 1, 3, 4).reshape(F, C, H, W), flow.reshape(F, H, W, 2), True)
+    ova = O.grid_sample_nearest(v.transpose(0, 2, 1, 3, 4).reshape(F, 1, H, W), flow.reshape(F, H, W, 2), True)
+    assert_close(N(xa).transpose(0, 2, 1, 3, 4).reshape(F, C, H, W), oxa, what="warp x")
+    assert_exact(N(va).transpose(0, 2, 1, 3, 4).reshape(F, 1, H, W), ova, what="warp v")
+
+
 @pytest.mark.parametrize("B,C,R,h,w,variant", [
     (2, 6, 20, 5, 7, "default"),      # R > 16: two passes of the slab kernels; odd hw (one pixel per lane)
     (1, 7, 3, 6, 8, "complete"),      # odd channel count (a wave's second channel is missing)
@@ -411,8 +427,9 @@ def test_context_matching_shape_corners(mods, B, C, R, h, w, variant):
     cot1 = rng.standard_normal(op.shape).astype(np.float32)
     cot2 = rng.standard_normal(om.shape).astype(np.float32)
     (g,) = torch.autograd.grad((p_in * T(cot1)).sum() + (c_mask * T(cot2)).sum(), [tcf])
-    og = O.context_matching_bwd(cf, v_t, v_al, cot1, cot2, True, variant)
-    assert_close(N(g), og, rtol=1e-3, atol=1e-4, what="g_c_feats")
+    with O.long_sums(np.float64):
+        og = O.context_matching_bwd(cf, v_t, v_al, cot1, cot2, True, variant)
+    assert_close(N(g), og, what="g_c_feats")
 
 
 @pytest.mark.parametrize("shape,dim", [((2, 3, 20, 5, 7), 2), ((3, 16, 33), 1), ((2, 1, 4, 9), 0), ((1, 5, 17, 3, 3), 2)])
@@ -497,28 +514,29 @@ def test_runner_step_functions_vs_oracle():
     gt256 = flow_gt[:, r_list]
     o_gt = [O.resize_flow(gt256, (16, 16)), O.resize_flow(gt256, (64, 64)), gt256]
     for k in range(3):
-        ox, ov = sets[k][0].numpy(), sets[k][1].numpy()
-        assert_close(N(xs[k]), ox, what="resize_set x")
+        assert_close(N(xs[k]), sets[k][0].numpy(), what="resize_set x")          # stock F.interpolate on two devices
+        assert_exact(N(vs[k]), sets[k][1].numpy(), what="resize_set v (nearest)")
+        # the oracle warps the SAME resized frames the HIP path warped (F.interpolate's last bit differs between devices;
+        # that is glue, not the path): every mask below is then bit-exact
+        ox, ov = N(xs[k]), N(vs[k])
         assert_exact(N(fl_gt[k]), o_gt[k], what="flow_gt scale %d" % k)
         oxa, ova = O.align_set(ox[:, :, r_list], ov[:, :, r_list], flows[k])
-        assert_close(N(xs_al[k]), oxa, rtol=1e-4, atol=2e-5, what="x_aligned scale %d" % k)
-        mism = (N(vs_al[k]) != ova).mean()
-        assert mism < 1e-4, "v_aligned scale %d: %.2e mismatching (interpolated inputs differ in the last bit)" % (k, mism)
+        assert_close(N(xs_al[k]), oxa, what="x_aligned scale %d" % k)
+        assert_exact(N(vs_al[k]), ova, what="v_aligned scale %d" % k)
         oxg, ovg = O.align_set(ox[:, :, r_list], ov[:, :, r_list], o_gt[k])
-        assert_close(N(xs_al_gt[k]), oxg, rtol=1e-4, atol=2e-5, what="x_aligned_gt scale %d" % k)
+        assert_close(N(xs_al_gt[k]), oxg, what="x_aligned_gt scale %d" % k)
+        assert_exact(N(vs_al_gt[k]), ovg, what="v_aligned_gt scale %d" % k)
         if k > 0:
-            ovm = O.v_map(ova, ov[:, :, t])
-            assert (N(v_maps[k - 1]) != ovm).mean() < 1e-4
-            ovmg = O.v_map(ovg, ov[:, :, t]) * flows_use.reshape(-1, 1, 1, 1, 1)
-            assert (N(v_maps_gt[k - 1]) != ovmg).mean() < 1e-4
+            assert_exact(N(v_maps[k - 1]), O.v_map(ova, ov[:, :, t]), what="v_map scale %d" % k)
+            assert_exact(N(v_maps_gt[k - 1]), O.v_map(ovg, ov[:, :, t]) * flows_use.reshape(-1, 1, 1, 1, 1), what="v_map_gt scale %d" % k)
     # gradients reach the predicted flows through the warps (what the reference's training exercises)
     loss = sum((xa * xa).sum() for xa in xs_al)
     grads = torch.autograd.grad(loss, tflows)
     for k in range(3):
-        ox, ov = sets[k][0].numpy(), sets[k][1].numpy()
+        ox, ov = N(xs[k]), N(vs[k])
         oxa, _ = O.align_set(ox[:, :, r_list], ov[:, :, r_list], flows[k])
         _, ogf = O.align_set_bwd(ox[:, :, r_list], ov[:, :, r_list], flows[k], 2 * oxa)
-        assert_close(N(grads[k]), ogf, rtol=1e-3, atol=1e-4, what="g_flow scale %d" % k)
+        assert_close(N(grads[k]), ogf, what="g_flow scale %d" % k)
     # inference unit
     xa, va, vm = runners.infer_step_propagate(_standin_model(tflows), T(x[:, :, t]), T(m[:, :, t]), T(x[:, :, r_list]), T(m[:, :, r_list]))
     oxa, ova = O.align_set(x[:, :, r_list], 1 - m[:, :, r_list], flows[2])

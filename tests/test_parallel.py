@@ -86,7 +86,30 @@ def _worker(rank, world_size, port, ret):
             ok_overlap &= in_flight >= len(ov.buckets) - 1      # every bucket completed by backward was launched by its hook
             ok_overlap &= all(torch.allclose(p.grad, r, rtol=1e-5, atol=1e-6) for p, r in zip(net2.parameters(), ref))
             ok_overlap &= all(any(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + 4 * f.numel() for f in ov._flat) for p in net2.parameters())
-        ret[rank] = (ok_data, ok_grad and ok_overlap)
+        # graphs that differ across ranks: rank 0's forward skips the MIDDLE module, so its hooks complete buckets
+        # 0 and 2 but not 1, while rank 1's complete 0, 1, 2.  Launched in completion order the ranks would pair bucket 2 with
+        # bucket 1 (same size: silently mixed gradients); launches must pair up bucket by bucket (index order on every rank).
+        torch.manual_seed(1)
+        a, b_, c_ = torch.nn.Linear(16, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 16)
+        net3 = torch.nn.ModuleList([a, b_, c_])
+        ov3 = parallel.GradientBuckets(net3.parameters(), bucket_mb=0.0005, overlap=True)
+        inp = torch.randn(4, 16)
+        ok_uneven = len(ov3.buckets) >= 3
+        for it in range(2):
+            net3.zero_grad(set_to_none=False)
+            h = inp + a(inp) if rank == 0 else inp + a(inp) + b_(inp)          # rank 0 never touches `b_`
+            loss = c_(h).pow(2).mean()
+            local = torch.autograd.grad(loss, list(net3.parameters()), allow_unused=True, retain_graph=True)
+            local = [torch.zeros_like(p) if g is None else g.clone() for p, g in zip(net3.parameters(), local)]
+            want = []
+            for g in local:                            # plain per-tensor average as the yardstick
+                t = g / world_size
+                dist.all_reduce(t)
+                want.append(t)
+            loss.backward()
+            ov3.reduce().wait()
+            ok_uneven &= all(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7) for p, w in zip(net3.parameters(), want))
+        ret[rank] = (ok_data, ok_grad and ok_overlap and ok_uneven)
     finally:
         dist.destroy_process_group()
 
