@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: aligned frame-pairs/sec on BASELINE.json configs[1]
-("utils.correlation all-pairs cost volume alone, 64x64 feature maps C=256, batch 16, fwd+bwd on 1 MI355X").
+"""Headline benchmark: BASELINE.json's metric, aligned frame-pairs/sec through corr + warp + match, forward and backward.
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A step = one forward + backward of compute_masked_4d_correlation over this rank's 16 synthetic frame pairs
-(inputs resident in HBM), through the drop-in function and the C ABI.  Ranks work on independent pairs: no
-data-path collective, weak scaling.  Rank 0 prints ONE JSON line with the whole-job pairs/s, the roofline of the
-dominant kernel (timed live with HIP events on the launch stream) and the CPU baseline (the numpy oracle on the
-host cores, bounded sample).
+One pass of the hot path takes PAIRS_PER_PASS = 640 synthetic frame pairs per GPU (inputs resident in HBM) through the three
+legs, each at the shape its BASELINE config names, through the drop-in functions and the C ABI:
+
+  corr   C2: compute_masked_4d_correlation fwd + bwd, 64x64 maps, C=256, batches of 16 pairs        (40 batches per pass)
+  warp   C3: the six align_set calls of train_step_propagate (ground-truth and predicted flow at 16 / 64 / 256 px) and the
+             grid-gradient backward of the three predicted ones, 128 pairs per batch                   (5 batches per pass)
+  match  C4: CPN temporal copying, 32 targets x 10 references at 240x424: affine warp (theta -> positions in the kernel) +
+             context matching incl. ref_importance, backward to theta and to the features              (2 batches per pass)
+
+A step is `inner` such passes (inner >= 1 is chosen so that the timed region lasts at least a second whatever --steps is).
+Ranks work on independent pairs: no data-path collective, weak scaling.  Rank 0 prints ONE JSON line: whole-job pairs/s,
+per-leg GPU time inside the timed region (HIP events on the launch stream), `legs`: every dominant kernel / entry point
+timed cache-cold through the C ABI against its roofline, `roofline`: the dominant kernel of the step, and `cpu_baseline`:
+the numpy oracle on the host cores per leg (all BLAS threads and one thread).
 """
 import argparse
+import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -28,89 +38,331 @@ if ROOT not in sys.path:
 PEAK_F32_MATRIX_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
 
-WORKLOADS = {
-    # name: (pairs per GPU, C, S)
-    "c2": dict(B=16, C=256, F=1, S=64, label="C2: utils.correlation all-pairs cost volume, 64x64 maps, C=256, batch 16, fwd+bwd"),
-}
+METRIC = "aligned frame-pairs/sec (corr+warp+match fwd+bwd) at 1/2/4/8 GPUs; % roofline"
+PAIRS_PER_PASS = 640
+CORR = dict(B=16, C=256, F=1, S=64)               # C2
+WARP = dict(B=32, R=4, S=256)                     # C3: 32 sequences x 4 references
+C4 = dict(B=32, C=128, R=10, h=30, w=53, H=240, W=424)
+N_CORR, N_WARP, N_C4 = PAIRS_PER_PASS // 16, PAIRS_PER_PASS // 128, PAIRS_PER_PASS // 320
 
 
-def make_inputs(w, dev, rank):
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    B, C, F, S = w["B"], w["C"], w["F"], w["S"]
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------ synthetic inputs
+def _blocky(g, shape, cell, p):
+    m = (torch.rand(*shape, generator=g) < p).float()
+    return m.repeat_interleave(cell, -2).repeat_interleave(cell, -1)
+
+
+def _ident(S):
+    lin = torch.linspace(-1, 1, S)
+    ys, xs = torch.meshgrid(lin, lin, indexing="ij")
+    return torch.stack([xs, ys], -1)
+
+
+def make_corr(dev, g):
+    B, C, F, S = CORR["B"], CORR["C"], CORR["F"], CORR["S"]
     xt = torch.randn(B, C, S, S, generator=g)
     xr = torch.randn(B, C, F, S, S, generator=g)
     vt = (torch.rand(B, 1, S, S, generator=g) >= 0.1).float()
     vr = (torch.rand(B, 1, F, S, S, generator=g) >= 0.1).float()
     cot = torch.randn(B, F, S, S, S, S, generator=g)
-    return [t.to(dev) for t in (xt, vt, xr, vr, cot)]
+    xt, vt, xr, vr, cot = [t.to(dev) for t in (xt, vt, xr, vr, cot)]
+    return dict(xt=xt.requires_grad_(True), vt=vt, xr=xr.requires_grad_(True), vr=vr, cot=cot)
 
 
-def time_dominant_kernel(w, dev, iters=20):
-    """Average duration of the forward contraction kernel (gemm_f32_kernel<128,128,...>) alone, HIP events on the launch stream."""
-    import ctypes
-    from master_thesis_amd import _lib
-    B, C, F, S = w["B"], w["C"], w["F"], w["S"]
-    P = S * S
-    xt, vt, xr, vr, _ = make_inputs(w, dev, 0)
-    lib = _lib.lib()
-    ws = torch.empty(lib.tcl_corr4d_fwd_workspace_bytes(B, C, F, P, 0), dtype=torch.uint8, device=dev)
-    out = torch.empty(B, F, P, P, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    sp = ctypes.c_void_p(stream.cuda_stream)
-    p = lambda t: ctypes.c_void_p(t.data_ptr())
-    _lib.call("tcl_corr4d_fwd", p(xt), p(vt.reshape(B, P)), p(xr), p(vr.reshape(B, F, P)), p(out), B, C, F, P, 0, p(ws), ws.numel(), sp)
-    for _ in range(3):
-        _lib.call("tcl_corr4d_contract", p(ws), p(out), B, C, F, P, 0, sp)
+def make_warp_set(dev, g):
+    """One C3 batch: frames / visibility at 16, 64, 256 px, ground-truth and predicted flows (smooth similarity + offset)."""
+    B, R = WARP["B"], WARP["R"]
+    d = {}
+    for s in (16, 64, 256):
+        d["x%d" % s] = torch.rand(B, 3, R, s, s, generator=g).to(dev)
+        d["v%d" % s] = _blocky(g, (B, 1, R, s // 8, s // 8), 8, 0.85).to(dev)
+        for name in ("gt", "pr"):
+            scale = 1 + 0.1 * (torch.rand(B, R, 1, 1, 1, generator=g) * 2 - 1)
+            shift = 0.2 * (torch.rand(B, R, 1, 1, 2, generator=g) * 2 - 1)
+            d["%s%d" % (name, s)] = (_ident(s)[None, None] * scale + shift).to(dev).contiguous()
+        d["pr%d" % s].requires_grad_(True)
+        d["cot%d" % s] = torch.randn(B, R, 3, s, s, generator=g).to(dev).transpose(1, 2)   # laid out like the warp's output
+    return d
+
+
+def make_c4_set(dev, g):
+    B, C, R, h, w, H, W = (C4[k] for k in ("B", "C", "R", "h", "w", "H", "W"))
+    d = {"r_list": [i for i in range(R + 1) if i != R // 2]}
+    d["x"] = torch.rand(B, 3, R + 1, H, W, generator=g).to(dev)
+    d["m"] = (1 - _blocky(g, (B, 1, R + 1, H // 8, W // 8), 8, 0.85)).to(dev)
+    d["theta"] = (torch.tensor([[1.0, 0, 0], [0, 1.0, 0]]) + 0.05 * torch.randn(B * R, 2, 3, generator=g)).to(dev).requires_grad_(True)
+    d["cf"] = (0.05 * torch.randn(B, C, R + 1, h, w, generator=g)).to(dev).requires_grad_(True)
+    d["cot_x"] = torch.randn(B, R, 3, H, W, generator=g).to(dev).transpose(1, 2)
+    d["cot_p"] = torch.randn(B, 2 * C + 1, h, w, generator=g).to(dev)
+    return d
+
+
+# ------------------------------------------------------------------------------------------------ the three legs (drop-in functions)
+def corr_leg(d):
+    from master_thesis_amd.utils import correlation
+    out = correlation.compute_masked_4d_correlation(d["xt"], d["vt"], d["xr"], d["vr"])
+    return torch.autograd.grad(out, [d["xt"], d["xr"]], grad_outputs=d["cot"])
+
+
+def warp_leg(d):
+    """thesis_dfpn/runner.py:118-120,132-134 and the backward of the reconstruction losses into the predicted flows."""
+    from master_thesis_amd.utils import flow
+    with torch.no_grad():
+        for s in (16, 64, 256):
+            flow.align_set(d["x%d" % s], d["v%d" % s], d["gt%d" % s])
+    outs = [flow.align_set(d["x%d" % s], d["v%d" % s], d["pr%d" % s])[0] for s in (16, 64, 256)]
+    return torch.autograd.grad(outs, [d["pr%d" % s] for s in (16, 64, 256)], grad_outputs=[d["cot%d" % s] for s in (16, 64, 256)])
+
+
+def c4_leg(d, module):
+    """models/cpn.py:280-295 (affine warp of frames + visibility) and :319 (context matching, normalize=False), with the
+    backward to theta (through the warp) and to the encoder features (through the matching)."""
+    from master_thesis_amd.models import cpn
+    x_al, v_al, _ = cpn.affine_align(d["x"], d["m"], None, d["theta"], d["r_list"], training=True)
+    t = C4["R"] // 2
+    p_in, c_mask, ref_imp = module(d["cf"], 1 - d["m"][:, :, t], v_al, normalize=False)
+    return torch.autograd.grad([x_al, p_in], [d["theta"], d["cf"]], grad_outputs=[d["cot_x"], d["cot_p"]])
+
+
+# ------------------------------------------------------------------------------------------------ cache-cold kernel timing (C ABI)
+def time_rotating(launchers, stream, rounds=6, warm=1):
+    """Average duration of one launch: the launchers (same call on different buffer sets, together far larger than the
+    256 MB Infinity Cache) run back to back, HIP events on the launch stream around the whole run."""
+    for _ in range(warm):
+        for fn in launchers:
+            fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
-    for _ in range(iters):
-        _lib.call("tcl_corr4d_contract", p(ws), p(out), B, C, F, P, 0, sp)
+    for _ in range(rounds):
+        for fn in launchers:
+            fn()
     e1.record(stream)
     e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * P * P * C * B * F            # SURVEY.md §8(d): 8.59 GFLOP per pair forward
-    del out, ws
-    return ms, flops
+    return e0.elapsed_time(e1) / (rounds * len(launchers))
 
 
-def cpu_baseline(w, budget_s=12.0):
-    """The numpy oracle (fwd + bwd of A1) on the host cores, on a bounded sample of the same workload."""
+def measure_legs(dev, corr, warp_sets, c4_sets):
+    """Every dominant kernel / entry point of the step alone, cache-cold, against its roofline (SURVEY 8d byte counts)."""
+    from master_thesis_amd import _lib
+    lib = _lib.lib()
+    stream = torch.cuda.current_stream(dev)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    legs = {}
+
+    def add(name, kernel, ms, nbytes=None, flops=None, note=None):
+        r = {"kernel": kernel, "ms_per_launch": round(ms, 4)}
+        if flops is not None:
+            tf = flops / (ms * 1e-3) / 1e12
+            r.update(bound="mfma", algorithmic_flops=int(flops), achieved=round(tf, 2), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
+                     frac=round(tf / PEAK_F32_MATRIX_TFLOPS, 4))
+        else:
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            r.update(bound="hbm", algorithmic_bytes=int(nbytes), achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                     frac=round(gbs / PEAK_HBM_GBS, 4))
+        if note:
+            r["note"] = note
+        legs[name] = r
+
+    # ---- corr (2.3 GB working set: cold by itself)
+    B, C, F, S = CORR["B"], CORR["C"], CORR["F"], CORR["S"]
+    P = S * S
+    xt, xr, vt, vr, cot = corr["xt"].detach(), corr["xr"].detach(), corr["vt"], corr["vr"], corr["cot"]
+    ws = torch.empty(lib.tcl_corr4d_fwd_workspace_bytes(B, C, F, P, 0), dtype=torch.uint8, device=dev)
+    ws2 = torch.empty(max(256, lib.tcl_corr4d_bwd_workspace_bytes(B, C, F, P, 0)), dtype=torch.uint8, device=dev)
+    out = torch.empty(B, F, P, P, device=dev)
+    gt, gr = torch.empty_like(xt), torch.empty_like(xr)
+    _lib.call("tcl_corr4d_fwd", _p(xt), _p(vt), _p(xr), _p(vr), _p(out), B, C, F, P, 0, _p(ws), ws.numel(), sp)
+    flops = 2.0 * P * P * C * B * F            # SURVEY.md 8(d): 8.59 GFLOP per pair forward
+    ms = time_rotating([lambda: _lib.call("tcl_corr4d_contract", _p(ws), _p(out), B, C, F, P, 0, sp)], stream, rounds=20, warm=3)
+    add("corr_fwd_contraction", "gemm_f32_kernel<128,128,2,2> (tcl_corr4d_contract)", ms, flops=flops)
+    ms = time_rotating([lambda: _lib.call("tcl_corr4d_bwd", _p(cot), _p(xt), _p(vt), _p(xr), _p(vr), _p(ws), _p(gt), _p(gr), B, C, F, P, 0,
+                                          _p(ws2), ws2.numel(), sp)], stream, rounds=10, warm=2)
+    add("corr_bwd", "2 x gemm_f32_kernel<256,128,4,2> + corr_normalise_bwd (tcl_corr4d_bwd)", ms, flops=2 * flops)
+    del out, ws, ws2, gt, gr
+
+    # ---- C3 warp at 256 px over the rotating sets
+    Bw, R, S = WARP["B"], WARP["R"], 256
+    npix = Bw * R * S * S
+    bufs = []
+    for d in warp_sets:
+        x, v, fl, cotw = d["x256"], d["v256"], d["pr256"].detach(), d["cot256"]
+        xo, vo = torch.empty(Bw, R, 3, S, S, device=dev), torch.empty(Bw, R, 1, S, S, device=dev)
+        bufs.append((x, v, fl, cotw, xo, vo, torch.empty_like(fl), torch.zeros_like(x)))
+    wsw = torch.empty(256, dtype=torch.uint8, device=dev)
+
+    def wfwd(b):
+        x, v, fl, cotw, xo, vo, gg, gx = b
+        return lambda: _lib.call("tcl_warp_fwd", _p(x), x.stride(0), x.stride(2), x.stride(1), _p(v), v.stride(0), v.stride(2), _p(fl), None,
+                                 _p(xo), xo.stride(0), xo.stride(1), xo.stride(2), _p(vo), vo.stride(0), vo.stride(1), Bw, R, 3, S, S, 1, 1, sp)
+
+    def wbwd(b, with_gx):
+        x, v, fl, cotw, xo, vo, gg, gx = b
+
+        def run():
+            if with_gx:
+                gx.zero_()
+            _lib.call("tcl_warp_bwd", _p(cotw), cotw.stride(0), cotw.stride(2), cotw.stride(1), _p(x), x.stride(0), x.stride(2), x.stride(1),
+                      _p(fl), None, _p(gx) if with_gx else None, gx.stride(0), gx.stride(2), gx.stride(1), _p(gg), None,
+                      Bw, R, 3, S, S, 1, _p(wsw), wsw.numel(), sp)
+        return run
+    add("warp_fwd_c3", "warp_fwd_kernel<grid,nearest,C3> (align_set, 128 pairs at 256x256)", time_rotating([wfwd(b) for b in bufs], stream),
+        nbytes=npix * (4 * 4 + 8 + 4 * 4), note="read x(3)+v(1)+grid(2), write x(3)+v(1)")
+    add("warp_bwd_grid_c3", "warp_bwd_kernel<grid,no gx> (what the reference's training exercises)",
+        time_rotating([wbwd(b, False) for b in bufs], stream), nbytes=npix * (3 * 4 + 3 * 4 + 8 + 8), note="read grad_out(3)+x(3)+grid(2), write grad_grid(2)")
+    add("warp_bwd_gx_c3", "warp_bwd_kernel<grid,gx> + memset of grad_x (scatter-add)",
+        time_rotating([wbwd(b, True) for b in bufs], stream), nbytes=npix * (3 * 4 + 3 * 4 + 8 + 8 + 3 * 4),
+        note="as above + write grad_x(3); north_star's scatter-add backward, not exercised by the reference")
+    del bufs
+
+    # ---- C4
+    B, C, R, h, w, H, W = (C4[k] for k in ("B", "C", "R", "h", "w", "H", "W"))
+    hw, npix = h * w, B * R * H * W
+    sets = []
+    for d in c4_sets:
+        xr_, vr_ = d["x"][:, :, d["r_list"]], (1 - d["m"])[:, :, d["r_list"]].contiguous()
+        vt_ = (1 - d["m"])[:, 0, R // 2].contiguous()
+        th = d["theta"].detach()
+        xo, vo = torch.empty(B, R, 3, H, W, device=dev), torch.empty(B, R, 1, H, W, device=dev)
+        cf = d["cf"].detach()
+        p_in, c_mask, c_match = torch.empty(B, 2 * C + 1, h, w, device=dev), torch.empty(B, h, w, device=dev), torch.empty(B, R, h, w, device=dev)
+        wsf = torch.empty(lib.tcl_ctx_workspace_bytes(B, C, R, h, w), dtype=torch.uint8, device=dev)
+        wsb = torch.empty(max(256, lib.tcl_ctx_bwd_workspace_bytes(B, C, R, h, w)), dtype=torch.uint8, device=dev)
+        wst = torch.empty(max(256, lib.tcl_warp_bwd_workspace_bytes(B, R, H, W, 1)), dtype=torch.uint8, device=dev)
+        sets.append(dict(xr=xr_, vr=vr_, vt=vt_, th=th, xo=xo, vo=vo, cf=cf, p_in=p_in, c_mask=c_mask, c_match=c_match, wsf=wsf, wsb=wsb, wst=wst,
+                         cot_x=d["cot_x"], cot_p=d["cot_p"], g_cf=torch.empty_like(cf), g_th=torch.empty_like(th),
+                         imp=torch.empty(B, 3, R + 1, H, W, device=dev)))
+
+    def afwd(q):
+        x, v, xo, vo = q["xr"], q["vr"], q["xo"], q["vo"]
+        return lambda: _lib.call("tcl_warp_fwd", _p(x), x.stride(0), x.stride(2), x.stride(1), _p(v), v.stride(0), v.stride(2), None, _p(q["th"]),
+                                 _p(xo), xo.stride(0), xo.stride(1), xo.stride(2), _p(vo), vo.stride(0), vo.stride(1), B, R, 3, H, W, 0, 2, sp)
+
+    def abwd(q):
+        x, go = q["xr"], q["cot_x"]
+        return lambda: _lib.call("tcl_warp_bwd", _p(go), go.stride(0), go.stride(2), go.stride(1), _p(x), x.stride(0), x.stride(2), x.stride(1),
+                                 None, _p(q["th"]), None, 0, 0, 0, None, _p(q["g_th"]), B, R, 3, H, W, 0, _p(q["wst"]), q["wst"].numel(), sp)
+
+    def cfwd(q):
+        return lambda: _lib.call("tcl_ctx_fwd", _p(q["cf"]), _p(q["vt"]), _p(q["vo"]), _p(q["p_in"]), _p(q["c_mask"]), _p(q["c_match"]),
+                                 B, C, R, h, w, H, W, 0, 0, _p(q["wsf"]), q["wsf"].numel(), sp)
+
+    def cbwd(q):
+        return lambda: _lib.call("tcl_ctx_bwd", _p(q["cot_p"]), None, _p(q["cf"]), _p(q["c_match"]), _p(q["wsf"]), _p(q["g_cf"]),
+                                 B, C, R, h, w, 0, 0, _p(q["wsb"]), q["wsb"].numel(), sp)
+
+    def imp(q):
+        return lambda: _lib.call("tcl_ref_importance", _p(q["c_match"]), _p(q["vt"]), _p(q["imp"]), B, R, h, w, H, W, 0, sp)
+    for q in sets:
+        afwd(q)()
+        cfwd(q)()
+    add("affine_warp_fwd_c4", "warp_fwd_kernel<theta,bilinear>0.5,C3> (320 pairs at 240x424)", time_rotating([afwd(q) for q in sets], stream),
+        nbytes=npix * (4 * 4 + 4 * 4), note="read x(3)+v(1), write x(3)+v(1); no grid in HBM")
+    add("affine_warp_bwd_theta_c4", "warp_bwd_kernel<theta,no gx> + warp_theta_reduce", time_rotating([abwd(q) for q in sets], stream),
+        nbytes=npix * (3 * 4 + 3 * 4), note="read grad_out(3)+x(3); theta gradient only (x is data in CPN training)")
+    ctx_fwd_bytes = B * (C * (R + 1) * hw * 4 + (R + 1) * H * W * 4 + (2 * C + 1) * hw * 4 + hw * 4)
+    add("ctx_fwd_c4", "ctx_resize_masks + ctx_sim + ctx_weights + ctx_aggregate (tcl_ctx_fwd, 32 targets)", time_rotating([cfwd(q) for q in sets], stream),
+        nbytes=ctx_fwd_bytes, note="SURVEY 8d: one read of c_feats + masks, one write of p_in (15.1 MB per target)")
+    add("ctx_bwd_c4", "ctx_bwd_dmatch + jacobian + finalize + feats (tcl_ctx_bwd)", time_rotating([cbwd(q) for q in sets], stream),
+        nbytes=B * (2 * C * (R + 1) * hw * 4 + (2 * C + 1) * hw * 4), note="read c_feats + grad p_in, write grad c_feats")
+    add("ref_importance_c4", "ref_importance_kernel<4>", time_rotating([imp(q) for q in sets], stream), nbytes=B * 3 * (R + 1) * H * W * 4 + B * H * W * 4,
+        note="write-only visualisation output (A9)")
+    return legs
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline (numpy oracle)
+def cpu_baseline(budget_s=24.0):
+    """The numpy oracle on the host cores, per leg, on bounded samples of the same workload; composite pairs/s = 1 / sum of the
+    legs' seconds per pair.  `cores`: the BLAS threads the correlation GEMMs used (everything else in numpy is one thread);
+    `one_thread`: the same with BLAS limited to one thread."""
     from oracle import tcl_oracle as O
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
     except Exception:
-        cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
-    C, F, S = w["C"], w["F"], w["S"]
-    nb = 2
+        threadpool_limits, cores = None, int(os.environ.get("OMP_NUM_THREADS", "1"))
     rng = np.random.default_rng(1234)
+    C, F, S = CORR["C"], CORR["F"], CORR["S"]
+    nb = 2
     xt = rng.standard_normal((nb, C, S, S)).astype(np.float32)
     xr = rng.standard_normal((nb, C, F, S, S)).astype(np.float32)
     vt = (rng.random((nb, 1, S, S)) >= 0.1).astype(np.float32)
     vr = (rng.random((nb, 1, F, S, S)) >= 0.1).astype(np.float32)
     cot = rng.standard_normal((nb, F, S, S, S, S)).astype(np.float32)
-    O.compute_masked_4d_correlation(xt[:1], vt[:1], xr[:1], vr[:1])  # warm-up (BLAS threads)
-    t0 = time.perf_counter()
-    pairs = 0
-    while True:
+
+    def corr():
         O.compute_masked_4d_correlation(xt, vt, xr, vr)
         O.compute_masked_4d_correlation_bwd(xt, vt, xr, vr, cot)
-        pairs += nb * F
-        el = time.perf_counter() - t0
-        if el > budget_s:
-            break
-    return dict(value=round(pairs / el, 3), unit="pairs/s", cores=int(cores), kind="port",
-                sample="%d pairs of the C2 workload (fwd+bwd, numpy oracle, %.1f s)" % (pairs, el))
+        return nb * F
+
+    s = 256
+    x = rng.random((1, 3, 2, s, s)).astype(np.float32)
+    v = (rng.random((1, 1, 2, s, s)) < 0.85).astype(np.float32)
+    ident = np.stack(np.meshgrid(np.linspace(-1, 1, s), np.linspace(-1, 1, s)), axis=-1).astype(np.float32)
+    fl = (ident[None, None] * 1.05 + 0.1).repeat(2, axis=1).astype(np.float32)
+    cw = rng.standard_normal(x.shape).astype(np.float32)
+
+    def warp():   # per pair at 256 px: two forward warps (ground-truth and predicted flow) and one backward; 16 / 64 px add 7 %
+        O.align_set(x, v, fl)
+        O.align_set(x, v, fl)
+        O.align_set_bwd(x, v, fl, cw)
+        return 2
+
+    B, Cc, R, h, w, H, W = 1, C4["C"], C4["R"], C4["h"], C4["w"], C4["H"], C4["W"]
+    r_list = [i for i in range(R + 1) if i != R // 2]
+    x4 = rng.random((B, 3, R + 1, H, W)).astype(np.float32)
+    m4 = (rng.random((B, 1, R + 1, H, W)) < 0.15).astype(np.float32)
+    th = (np.array([[1, 0, 0], [0, 1, 0]], np.float32)[None] + 0.05 * rng.standard_normal((B * R, 2, 3))).astype(np.float32)
+    cf = (0.05 * rng.standard_normal((B, Cc, R + 1, h, w))).astype(np.float32)
+    cx = rng.standard_normal((B, 3, R, H, W)).astype(np.float32)
+    cp, cm = rng.standard_normal((B, 2 * Cc + 1, h, w)).astype(np.float32), np.zeros((B, 1, h, w), np.float32)
+
+    def match():
+        _, va, _ = O.cpn_align(x4, m4, None, th, r_list)
+        O.cpn_align_bwd(x4, th, r_list, cx)
+        O.context_matching(cf, 1 - m4[:, :, R // 2], va, False, "default")
+        O.context_matching_bwd(cf, 1 - m4[:, :, R // 2], va, cp, cm, False, "default")
+        return R
+
+    def rate(fn, budget):
+        fn()
+        t0, n = time.perf_counter(), 0
+        while True:
+            n += fn()
+            el = time.perf_counter() - t0
+            if el > budget:
+                return n / el, n, el
+
+    share = budget_s / 4.5
+    legs, sample = {}, []
+    for name, fn, b in (("corr", corr, share * 1.5), ("warp", warp, share), ("match", match, share)):
+        r, n, el = rate(fn, b)
+        legs[name] = round(r, 3)
+        sample.append("%s: %d pairs in %.1f s" % (name, n, el))
+    composite = 1.0 / sum(1.0 / legs[k] for k in legs)
+    res = dict(value=round(composite, 3), unit="pairs/s", cores=int(cores), kind="port", legs_pairs_per_s=legs,
+               sample="numpy oracle, fwd+bwd per leg at the bench's shapes (" + "; ".join(sample) + "); composite = 1 / sum of seconds per pair")
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            r1, n, el = rate(corr, share)
+        one = dict(legs)
+        one["corr"] = round(r1, 3)
+        res["one_thread"] = dict(value=round(1.0 / sum(1.0 / one[k] for k in one), 3), legs_pairs_per_s=one, cores=1)
+    return res
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the cache-cold per-kernel measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,29 +384,60 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from master_thesis_amd.models import cpn
     from master_thesis_amd.utils import correlation
 
-    w = WORKLOADS[args.workload]
-    xt, vt, xr, vr, cot = make_inputs(w, dev, rank)
-    xt.requires_grad_(True)
-    xr.requires_grad_(True)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    corr = make_corr(dev, g)
+    warp_sets = [make_warp_set(dev, g) for _ in range(N_WARP)]
+    c4_sets = [make_c4_set(dev, g) for _ in range(N_C4)]
+    module = cpn.CPNContextMatchingDefault()
+    stream = torch.cuda.current_stream(dev)
+    marks = []   # (e0, e1, e2, e3) per pass: leg boundaries on the launch stream
 
-    def step():
-        out = correlation.compute_masked_4d_correlation(xt, vt, xr, vr)
-        g = torch.autograd.grad(out, [xt, xr], grad_outputs=cot)
-        return g
+    def one_pass(record):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
+        if record:
+            ev[0].record(stream)
+        for _ in range(N_CORR):
+            corr_leg(corr)
+        if record:
+            ev[1].record(stream)
+        for d in warp_sets:
+            warp_leg(d)
+        if record:
+            ev[2].record(stream)
+        for d in c4_sets:
+            c4_leg(d, module)
+        if record:
+            ev[3].record(stream)
+            marks.append(ev)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # warm-up; the last warm-up pass also sizes `inner` so that the timed region lasts >= 1 s whatever --steps is
+    one_pass(False)
+    barrier()
+    t0 = time.perf_counter()
+    one_pass(False)
+    barrier()
+    t_pass = time.perf_counter() - t0
+    inner = max(1, int(math.ceil(1.0 / (max(args.steps, 1) * t_pass))))
+    if world > 1:
+        ti = torch.tensor([inner], device="cpu" if rehearse else dev, dtype=torch.int64)
+        dist.all_reduce(ti, op=dist.ReduceOp.MAX)
+        inner = int(ti.item())
+    for _ in range(max(0, args.warmup - 2)):
+        for _ in range(inner):
+            one_pass(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        for _ in range(inner):
+            one_pass(True)
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
@@ -162,16 +445,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    pairs_per_step = w["B"] * w["F"] * world
+    n_pass = args.steps * inner
+    leg_ms = {k: sum(ev[i].elapsed_time(ev[i + 1]) for ev in marks) / len(marks) for i, k in enumerate(("corr", "warp", "match"))}
 
-    # the other arithmetic variants of the same path, same workload, this rank only (reported beside the headline,
-    # never as `value`): bf16x3 = hi/lo split on bf16 MFMA, meets the fp32 bar; bf16 = plain bf16 operands, 1e-2 bar
+    # the other arithmetic variants of the correlation leg, this rank only (reported beside the headline, never as `value`):
+    # bf16x3 = hi/lo split on bf16 MFMA, meets the fp32 bar; bf16 = plain bf16 operands, 1e-2 bar
     variants = {}
-    if not args.no_variants:
+    if not args.no_variants and rank == 0:
         for prec in ("bf16x3", "bf16"):
             def vstep():
-                out = correlation.compute_masked_4d_correlation(xt, vt, xr, vr, precision=prec)
-                return torch.autograd.grad(out, [xt, xr], grad_outputs=cot)
+                out = correlation.compute_masked_4d_correlation(corr["xt"], corr["vt"], corr["xr"], corr["vr"], precision=prec)
+                return torch.autograd.grad(out, [corr["xt"], corr["xr"]], grad_outputs=corr["cot"])
             for _ in range(2):
                 vstep()
             torch.cuda.synchronize()
@@ -180,19 +464,17 @@ def main():
                 vstep()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - tv) / 10 * 1e3
-            variants[prec] = {"ms_per_step": round(ms, 4), "pairs_per_s_per_gpu": round(w["B"] * w["F"] / ms * 1e3, 1),
-                              "tolerance": "fp32 bar (1e-4)" if prec == "bf16x3" else "1e-2"}
+            variants[prec] = {"corr_leg_ms_per_16_pairs": round(ms, 4), "tolerance": "fp32 bar (1e-4)" if prec == "bf16x3" else "1e-2"}
     result = None
     if rank == 0:
-        kms, kflops = time_dominant_kernel(w, dev)
-        achieved = kflops / (kms * 1e-3) / 1e12
+        legs = None if args.no_legs else measure_legs(dev, corr, warp_sets, c4_sets)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("gemm_f32_fwd_bytes_per_launch")
         result = {
-            "metric": "aligned frame-pairs/sec (corr fwd+bwd)",
-            "value": round(pairs_per_step * args.steps / el, 2),
+            "metric": METRIC,
+            "value": round(PAIRS_PER_PASS * n_pass * world / el, 2),
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -203,16 +485,22 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": w["label"], "pairs_per_gpu": w["B"] * w["F"], "C": w["C"], "map": "%dx%d" % (w["S"], w["S"]),
-                       "precision": "fp32 MFMA (exact)", "sharding": "independent pairs per rank, no collective"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,2,2> (tcl_corr4d_contract, forward contraction)",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "ms_per_launch": round(kms, 4), "traffic": traffic},
+            "config": {"workload": "C2 + C3 + C4 legs of one pass: corr 64x64 C=256 (40 x 16 pairs) + align_set x6 at 16/64/256 px with grid-gradient "
+                                   "backward (5 x 128 pairs) + CPN affine warp and context matching at 240x424, 10 references (2 x 320 pairs), fwd+bwd",
+                       "pairs_per_pass_per_gpu": PAIRS_PER_PASS, "passes_per_step": inner, "timed_region_s": round(el, 3),
+                       "precision": "fp32 (exact fp32 MFMA for the contraction)", "sharding": "independent pairs per rank, no collective"},
+            "leg_ms_per_pass": {k: round(v, 4) for k, v in leg_ms.items()},
         }
+        if legs:
+            k = legs["corr_fwd_contraction"]
+            result["roofline"] = {"bound": "mfma", "kernel": k["kernel"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"],
+                                  "frac": k["frac"], "ms_per_launch": k["ms_per_launch"], "traffic": traffic,
+                                  "share_of_step": round(N_CORR * k["ms_per_launch"] / sum(leg_ms.values()), 3)}
+            result["legs"] = legs
         if variants:
             result["variants"] = variants
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(w)
+            result["cpu_baseline"] = cpu_baseline()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
