@@ -336,6 +336,144 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ tiled backward
+// Backward over TILE_H x TILE_W output pixels per block: each of the four waves walks TILE_K consecutive rows of a
+// 64-pixel-wide column strip, one column per lane.  Used for the two cases the one-pixel-per-lane kernel handles badly:
+//   * the input gradient (scatter-add).  Float atomics execute at the memory side at one chip-wide rate, ~1.3 TB/s of added
+//     bytes in 64-byte requests, whatever their placement (MI355X_MICROARCH.md, Global float atomics); four scattered adds per
+//     pixel and channel are 4x the bytes of the gradient itself.  Under a smooth flow the four output pixels around a source
+//     pixel are lane neighbours (east / west) and consecutive rows of one lane (north / south), so their contributions are
+//     summed in registers first: a lane keeps the SOUTH-row contributions of its pixel pending and adds them to the NORTH-row
+//     contributions of its next pixel when that one lands exactly one source row lower at the same column (otherwise the
+//     pending pair is flushed as it is), and lane l hands its east value to lane l+1's west one when they share an address.
+//     What leaves is ~(1 + 1/TILE_K) adds per source pixel and channel, lanes along a row.  Any flow is handled: where the
+//     merges do not apply the adds simply go out unmerged.
+//   * the theta gradient: six block sums per 2048 pixels instead of per 256 (the reductions, not HBM, bound the small kernel).
+constexpr int TILE_W = 64, TILE_K = 8, TILE_H = 4 * TILE_K;
+
+// One row pair (row r, columns xi and xi + 1) of contributions per lane -> global atomics, after the east -> west hand-over
+// between neighbouring lanes.  `on`: this lane has a pair to emit; vw / ve: its west / east column lies inside the image.
+// Every lane of the wave must call (shuffles).  r and xi fit 14 bits here (H, W < 16384: checked by the host).
+template <int NC>
+__device__ __forceinline__ void emit_row_pair(float *gbase, int64_t sc, int W, bool on, int r, int xi, bool vw, bool ve,
+                                              float (&w)[NC], float (&e)[NC], int nc) {
+  const int lane = threadIdx.x & 63;
+  const int key = on ? ((xi & 0x3fff) | ((r & 0x3fff) << 14)) : -1;
+  const int kx = on ? ((vw ? 1 : 0) | (ve ? 2 : 0)) : 0;
+  const int key_up = __shfl_up(key, 1, 64), kx_up = __shfl_up(kx, 1, 64);
+  const int key_dn = __shfl_down(key, 1, 64), kx_dn = __shfl_down(kx, 1, 64);
+  // pair (p, q = p + 1): same row, xi_q == xi_p + 1 (no wrap at 14 bits), east of p valid exactly when west of q is
+  auto pair_ok = [](int kp, int xp, int kq, int xq) {
+    return kp != -1 && kq != -1 && (kq - kp) == 1 && ((kp & 0x3fff) != 0x3fff) && (((xp >> 1) & 1) == (xq & 1));
+  };
+  const bool hand_east = lane < 63 && pair_ok(key, kx, key_dn, kx_dn);
+  const bool take_west = lane > 0 && pair_ok(key_up, kx_up, key, kx);
+  float *g = gbase + r * W + xi;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float e_up = __shfl_up(e[c], 1, 64);
+    const float wv = take_west ? w[c] + e_up : w[c];
+    if (on && c < nc) {
+      if (vw) atomicAdd(g + c * sc, wv);
+      if (ve && !hand_east) atomicAdd(g + c * sc + 1, e[c]);
+    }
+  }
+}
+
+template <bool HAS_THETA, bool HAS_GX, bool C3>
+__global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int tiles_x, int tiles_y) {
+  __shared__ float red[4][6];
+  const int H = a.H, W = a.W, HW = H * W;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int trow = tile / tiles_x;
+  const int lx = threadIdx.x & 63, ly = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ty0 = trow * TILE_H + ly * TILE_K, tx0 = (tile - trow * tiles_x) * TILE_W;   // this wave's strip: rows ty0 .. ty0 + TILE_K - 1
+  const int b = n / a.NF, f = n - b * a.NF;
+  const bool ac = a.align_corners != 0;
+  const float mx = ac ? 0.5f * (float)(W - 1) : 0.5f * (float)W;
+  const float my = ac ? 0.5f * (float)(H - 1) : 0.5f * (float)H;
+  const float *xp = a.x + b * a.x_sb + f * a.x_sf;
+  const float *gp = a.go + b * a.go_sb + f * a.go_sf;
+  float *gxb = HAS_GX ? a.gx + b * a.gx_sb + f * a.gx_sf : nullptr;
+  const int x = min(tx0 + lx, W - 1);
+  const bool okx = tx0 + lx < W;
+  const int C = C3 ? 3 : a.C;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < C; c0 += FWD_MAXC) {   // one pass for the reference's three-channel frames
+    const int nc = min(FWD_MAXC, C - c0);
+    // pending south-row pair of the previous pixel of this lane
+    bool p_on = false, p_vw = false, p_ve = false;
+    int p_r = 0, p_xi = 0;
+    float p_w[FWD_MAXC], p_e[FWD_MAXC];
+#pragma unroll
+    for (int c = 0; c < FWD_MAXC; ++c) p_w[c] = p_e[c] = 0.f;
+#pragma unroll 2
+    for (int k = 0; k < TILE_K; ++k) {
+      const int yy = ty0 + k;   // wave-uniform
+      const bool ok = okx & (yy < H);
+      const int y = min(yy, H - 1), pix = y * W + x;
+      float ix, iy, xs, ys;
+      sample_pos<HAS_THETA>(a.grid, a.theta, n, y, x, H, W, a.stepx, a.stepy, ac, ix, iy, xs, ys);
+      const Taps t = make_taps(ix, iy, H, W);
+      float g[FWD_MAXC];
+      TapVals tv[FWD_MAXC];
+#pragma unroll
+      for (int c = 0; c < FWD_MAXC; ++c) {
+        const int cc = min(c0 + c, C - 1);
+        g[c] = gp[cc * a.go_sc + pix];
+        tv[c] = fetch_taps<true>(xp + cc * a.x_sc, t, W);
+      }
+      float gix = 0.f, giy = 0.f, n_w[FWD_MAXC], n_e[FWD_MAXC], s_w[FWD_MAXC], s_e[FWD_MAXC];
+#pragma unroll
+      for (int c = 0; c < FWD_MAXC; ++c) {
+        float vnw, vne, vsw, vse;
+        select_taps<true>(tv[c], t, vnw, vne, vsw, vse);
+        const float gc = (ok & (c < nc)) ? g[c] : 0.f;
+        gix += gc * ((vne - vnw) * t.sy + (vse - vsw) * t.ny);
+        giy += gc * ((vsw - vnw) * t.ex + (vse - vne) * t.wx);
+        n_w[c] = gc * t.nw; n_e[c] = gc * t.ne; s_w[c] = gc * t.sw; s_e[c] = gc * t.se;
+      }
+      if (HAS_GX) {
+        const bool cols = t.xw | t.xe;
+        // the pending pair sits on source row p_r at columns p_xi, p_xi + 1: it merges into this pixel's north pair when that
+        // is the same row and column (validity of the row and of the columns is then the same on both sides)
+        const bool merge = p_on & ok & t.yn & cols & (t.yi == p_r) & (t.xi == p_xi);
+        if (__any(p_on & !merge)) emit_row_pair<FWD_MAXC>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on & !merge, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
+#pragma unroll
+        for (int c = 0; c < FWD_MAXC; ++c) {
+          n_w[c] += merge ? p_w[c] : 0.f;
+          n_e[c] += merge ? p_e[c] : 0.f;
+        }
+        emit_row_pair<FWD_MAXC>(gxb + c0 * a.gx_sc, a.gx_sc, W, ok & t.yn & cols, t.yi, t.xi, t.xw, t.xe, n_w, n_e, nc);
+        p_on = ok & t.ys & cols; p_r = t.yi + 1; p_xi = t.xi; p_vw = t.xw; p_ve = t.xe;
+#pragma unroll
+        for (int c = 0; c < FWD_MAXC; ++c) { p_w[c] = s_w[c]; p_e[c] = s_e[c]; }
+      }
+      gix *= mx; giy *= my;
+      if (HAS_THETA) {
+        if (ok) { acc[0] += gix * xs; acc[1] += gix * ys; acc[2] += gix; acc[3] += giy * xs; acc[4] += giy * ys; acc[5] += giy; }
+      } else if (a.g_grid && ok) {
+        float *o = a.g_grid + ((int64_t)n * HW + pix) * 2;
+        if (C3) st_stream2(o, gix, giy);
+        else if (c0 == 0) { o[0] = gix; o[1] = giy; }
+        else { o[0] += gix; o[1] += giy; }   // generic channel counts: later groups add to this lane's own earlier store
+      }
+    }
+    if (HAS_GX && __any(p_on)) emit_row_pair<FWD_MAXC>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
+  }
+  if (HAS_THETA && a.partial) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float s = wave_sum(acc[k]);
+      if (lx == 0) red[ly][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+      a.partial[((int64_t)n * (tiles_x * tiles_y) + tile) * 6 + threadIdx.x] =
+          (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 // g_theta[n][k] = sum over the image's blocks, in block order (deterministic)
 __global__ void warp_theta_reduce_kernel(const float *partial, float *g_theta, int N, int nblk) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -468,7 +606,25 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
     else if (W >= 2) hipLaunchKernelGGL((warp_bwd_kernel<TH, GX, true, false>), grd, blk, 0, s, a);       \
     else hipLaunchKernelGGL((warp_bwd_kernel<TH, GX, false, false>), grd, blk, 0, s, a);                  \
   } while (0)
-  if (theta) {
+  // images of at least one tile: the tiled kernel for the input gradient (LDS-staged scatter-add) and for the theta gradient
+  // (one set of block sums per 2048 pixels); the grid-gradient-only case stays on the one-pixel-per-lane kernel
+  const bool tiled = W >= TILE_W && H >= TILE_H && W < 16384 && H < 16384 && (g_x || theta);
+  int nblk = per;
+  if (tiled) {
+    const int tx = (int)cdiv(W, TILE_W), ty = (int)cdiv(H, TILE_H);
+    nblk = tx * ty;   // <= cdiv(H * W, 256) for H >= 32, W >= 64: the theta workspace is large enough
+    const dim3 tg((unsigned)nblk, (unsigned)N);
+#define TCL_LAUNCH_WTILE(TH, GX)                                                                          \
+  do {                                                                                                     \
+    if (C == 3) hipLaunchKernelGGL((warp_bwd_tile_kernel<TH, GX, true>), tg, blk, 0, s, a, tx, ty);        \
+    else hipLaunchKernelGGL((warp_bwd_tile_kernel<TH, GX, false>), tg, blk, 0, s, a, tx, ty);              \
+  } while (0)
+    if (theta) {
+      if (g_x) TCL_LAUNCH_WTILE(true, true);
+      else TCL_LAUNCH_WTILE(true, false);
+    } else TCL_LAUNCH_WTILE(false, true);
+#undef TCL_LAUNCH_WTILE
+  } else if (theta) {
     if (g_x) TCL_LAUNCH_WBWD(true, true);
     else TCL_LAUNCH_WBWD(true, false);
   } else {
@@ -479,7 +635,7 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
   int rc = check_launch("tcl_warp_bwd");
   if (rc != TCL_OK) return rc;
   if (g_theta) {
-    hipLaunchKernelGGL(warp_theta_reduce_kernel, dim3((unsigned)cdiv(N * 6, 256)), dim3(256), 0, s, partial, g_theta, N, per);
+    hipLaunchKernelGGL(warp_theta_reduce_kernel, dim3((unsigned)cdiv(N * 6, 256)), dim3(256), 0, s, partial, g_theta, N, nblk);
     rc = check_launch("tcl_warp_bwd(theta reduce)");
   }
   return rc;

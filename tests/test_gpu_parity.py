@@ -382,6 +382,49 @@ def test_warp_generic_channel_counts(C, F, H, W):
     assert_close(N(gf), ogf, what="warp g_flow")
 
 
+@pytest.mark.parametrize("C,H,W,scale,rot,jitter", [
+    (3, 64, 128, 1.0, 0.0, 0.0),       # exact identity: every north / south and east / west pair merges
+    (3, 96, 200, 1.08, 0.15, 0.001),   # upscaling + rotation: columns skip, rows drift
+    (3, 70, 90, 0.8, -0.2, 0.002),     # downscaling: two output pixels share a source column / row
+    (5, 40, 70, 1.03, 0.05, 0.0),      # generic channel count: two channel groups, grid gradient accumulated over them
+    (1, 33, 65, 0.95, 0.3, 0.01),      # ragged tiles (one row / one column beyond the tile)
+    (3, 64, 64, 1.0, 0.0, 1.5),        # wild flow: nothing merges
+])
+def test_warp_tiled_backward_smooth_flows(C, H, W, scale, rot, jitter):
+    """The tiled backward (images of at least 32 x 64) sums the contributions of neighbouring output pixels in registers before
+    the float atomics; smooth flows are where those merges fire.  Grid and theta sources, input + grid / theta gradients."""
+    from master_thesis_amd import _lib, _ops
+    rng = np.random.default_rng(C * 1000 + H + W)
+    B, F = 2, 2
+    x = rng.random((B, C, F, H, W)).astype(np.float32)
+    cot = rng.standard_normal((B, C, F, H, W)).astype(np.float32)
+    xs, ys = np.meshgrid(np.linspace(-1, 1, W), np.linspace(-1, 1, H))
+    flow = np.empty((B * F, H, W, 2), np.float32)
+    theta = np.empty((B * F, 2, 3), np.float32)
+    for i in range(B * F):
+        a, s_ = rot * (1 + 0.1 * i), scale * (1 + 0.01 * i)
+        tx, ty = 0.05 * i, -0.03 * i
+        theta[i] = [[s_ * np.cos(a), -s_ * np.sin(a), tx], [s_ * np.sin(a), s_ * np.cos(a), ty]]
+        flow[i] = np.stack([theta[i, 0, 0] * xs + theta[i, 0, 1] * ys + tx, theta[i, 1, 0] * xs + theta[i, 1, 1] * ys + ty], -1)
+    flow = (flow + jitter * rng.standard_normal(flow.shape)).astype(np.float32)
+    # grid source (align_corners = True, as align_set)
+    tx_, tf = T(x, True), T(flow, True)
+    xa, _ = _ops.WarpFn.apply(tx_, None, tf, None, True, _lib.VMODE_NONE)
+    gx, gf = torch.autograd.grad((xa * T(cot)).sum(), [tx_, tf])
+    src = x.transpose(0, 2, 1, 3, 4).reshape(B * F, C, H, W)
+    ogx, ogf = O.grid_sample_bilinear_bwd(src, flow, True, cot.transpose(0, 2, 1, 3, 4).reshape(B * F, C, H, W))
+    assert_close(N(gx).transpose(0, 2, 1, 3, 4).reshape(B * F, C, H, W), ogx, what="g_x (grid)")
+    assert_close(N(gf), ogf, what="g_grid")
+    # theta source (align_corners = False, as CPNet.align)
+    tx_, tth = T(x, True), T(theta, True)
+    xa, _ = _ops.WarpFn.apply(tx_, None, None, tth, False, _lib.VMODE_NONE)
+    gx, gth = torch.autograd.grad((xa * T(cot)).sum(), [tx_, tth])
+    grid = O.affine_grid(theta, H, W, False)
+    ogx, ogg = O.grid_sample_bilinear_bwd(src, grid, False, cot.transpose(0, 2, 1, 3, 4).reshape(B * F, C, H, W))
+    assert_close(N(gx).transpose(0, 2, 1, 3, 4).reshape(B * F, C, H, W), ogx, what="g_x (theta)")
+    assert_close(N(gth), O.affine_grid_bwd(ogg, H, W, False), what="g_theta")
+
+
 def test_warp_many_large_frames_one_launch():
     """200 frames of 300 x 300 = 352 chunks x 200 frames > 65535, each frame with its own source (gf == 1): the
     forward used to reject what the backward accepts."""
