@@ -145,7 +145,7 @@ def time_rotating(launchers, stream, rounds=6, warm=1):
     return e0.elapsed_time(e1) / (rounds * len(launchers))
 
 
-def measure_legs(dev, corr, warp_sets, c4_sets):
+def measure_legs(dev, corr, warp_sets, c4_sets, groups=("corr", "warp", "c4")):
     """Every dominant kernel / entry point of the step alone, cache-cold, against its roofline (SURVEY 8d byte counts)."""
     from master_thesis_amd import _lib
     lib = _lib.lib()
@@ -167,6 +167,17 @@ def measure_legs(dev, corr, warp_sets, c4_sets):
             r["note"] = note
         legs[name] = r
 
+    if "corr" in groups:
+        _legs_corr(dev, corr, add, lib, stream, sp)
+    if "warp" in groups:
+        _legs_warp(dev, warp_sets, add, stream, sp)
+    if "c4" in groups:
+        _legs_c4(dev, c4_sets, add, lib, stream, sp)
+    return legs
+
+
+def _legs_corr(dev, corr, add, lib, stream, sp):
+    from master_thesis_amd import _lib
     # ---- corr (2.3 GB working set: cold by itself)
     B, C, F, S = CORR["B"], CORR["C"], CORR["F"], CORR["S"]
     P = S * S
@@ -184,6 +195,9 @@ def measure_legs(dev, corr, warp_sets, c4_sets):
     add("corr_bwd", "2 x gemm_f32_kernel<256,128,4,2> + corr_normalise_bwd (tcl_corr4d_bwd)", ms, flops=2 * flops)
     del out, ws, ws2, gt, gr
 
+
+def _legs_warp(dev, warp_sets, add, stream, sp):
+    from master_thesis_amd import _lib
     # ---- C3 warp at 256 px over the rotating sets
     Bw, R, S = WARP["B"], WARP["R"], 256
     npix = Bw * R * S * S
@@ -218,6 +232,9 @@ def measure_legs(dev, corr, warp_sets, c4_sets):
         note="as above + write grad_x(3); north_star's scatter-add backward, not exercised by the reference")
     del bufs
 
+
+def _legs_c4(dev, c4_sets, add, lib, stream, sp):
+    from master_thesis_amd import _lib
     # ---- C4
     B, C, R, h, w, H, W = (C4[k] for k in ("B", "C", "R", "h", "w", "H", "W"))
     hw, npix = h * w, B * R * H * W
@@ -270,7 +287,6 @@ def measure_legs(dev, corr, warp_sets, c4_sets):
         nbytes=B * (2 * C * (R + 1) * hw * 4 + (2 * C + 1) * hw * 4), note="read c_feats + grad p_in, write grad c_feats")
     add("ref_importance_c4", "ref_importance_kernel<4>", time_rotating([imp(q) for q in sets], stream), nbytes=B * 3 * (R + 1) * H * W * 4 + B * H * W * 4,
         note="write-only visualisation output (A9)")
-    return legs
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (numpy oracle)
@@ -363,6 +379,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the cache-cold per-kernel measurements")
+    ap.add_argument("--legs-only", default="", help="development: only the cache-cold measurements of these groups (corr,warp,c4), one line per leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -388,6 +405,13 @@ def main():
     from master_thesis_amd.utils import correlation
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    if args.legs_only:
+        groups = tuple(args.legs_only.split(","))
+        legs = measure_legs(dev, make_corr(dev, g) if "corr" in groups else None, [make_warp_set(dev, g) for _ in range(N_WARP)] if "warp" in groups else None,
+                            [make_c4_set(dev, g) for _ in range(N_C4)] if "c4" in groups else None, groups)
+        for k, v in legs.items():
+            print("%-28s %8.4f ms  %8.1f %s  frac %.3f" % (k, v["ms_per_launch"], v["achieved"], v["unit"], v["frac"]), flush=True)
+        return
     corr = make_corr(dev, g)
     warp_sets = [make_warp_set(dev, g) for _ in range(N_WARP)]
     c4_sets = [make_c4_set(dev, g) for _ in range(N_C4)]

@@ -40,6 +40,10 @@ constexpr float kNormEps = 1e-9f;
 typedef float tcl_f2 __attribute__((ext_vector_type(2)));
 typedef float tcl_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_stream(float *p, float v) {
+#ifdef TCL_ABL_NOSTORE   // diagnostic side build: keep the value alive, store (almost) never
+  if (v == 1.2345e-30f) *p = v;
+  return;
+#endif
 #ifdef TCL_NO_STREAM_STORES
   *p = v;
 #else

@@ -354,8 +354,10 @@ constexpr int TILE_W = 64, TILE_K = 8, TILE_H = 4 * TILE_K;
 // One row pair (row r, columns xi and xi + 1) of contributions per lane -> global atomics, after the east -> west hand-over
 // between neighbouring lanes.  `on`: this lane has a pair to emit; vw / ve: its west / east column lies inside the image.
 // Every lane of the wave must call (shuffles).  r and xi fit 14 bits here (H, W < 16384: checked by the host).
-template <int NC>
-__device__ __forceinline__ void emit_row_pair(float *gbase, int64_t sc, int W, bool on, int r, int xi, bool vw, bool ve,
+// Returns whether this lane still holds an EAST value that no neighbour took (the caller queues it, see LeftoverQueue);
+// with DIRECT_EAST those are added here instead.
+template <int NC, bool DIRECT_EAST>
+__device__ __forceinline__ bool emit_row_pair(float *gbase, int64_t sc, int W, bool on, int r, int xi, bool vw, bool ve,
                                               float (&w)[NC], float (&e)[NC], int nc) {
   const int lane = threadIdx.x & 63;
   const int key = on ? ((xi & 0x3fff) | ((r & 0x3fff) << 14)) : -1;
@@ -375,10 +377,56 @@ __device__ __forceinline__ void emit_row_pair(float *gbase, int64_t sc, int W, b
     const float wv = take_west ? w[c] + e_up : w[c];
     if (on && c < nc) {
       if (vw) atomicAdd(g + c * sc, wv);
-      if (ve && !hand_east) atomicAdd(g + c * sc + 1, e[c]);
+      if (DIRECT_EAST && ve && !hand_east) atomicAdd(g + c * sc + 1, e[c]);
     }
   }
+  return on && ve && !hand_east;
 }
+
+// Leftover east values (the last lane's, and those at column gaps of an upscaling flow or at repeated columns of a
+// downscaling one) are few per row, but a float-atomic wave instruction costs the CU its ~50 ns whatever the number of active
+// lanes (MI355X_MICROARCH.md, Global float atomics: one wave instruction per ~50 ns per CU).  They are therefore compacted
+// into a wave-level queue held in registers, one slot per lane (slot 63 is the dump for lanes that have nothing to push), and
+// leave as one instruction per channel when the queue cannot take the next row's.
+template <int NC>
+struct LeftoverQueue {
+  int off;        // element offset of the slot's address from the channel-0 plane
+  float v[NC];
+  int n;          // slots in use (wave-uniform)
+  __device__ __forceinline__ void init() {
+    off = 0; n = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = 0.f;
+  }
+  __device__ __forceinline__ void flush(float *gbase, int64_t sc, int nc) {
+    const int lane = threadIdx.x & 63;
+    if (lane < n) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        if (c < nc) atomicAdd(gbase + off + c * sc, v[c]);
+    }
+    n = 0;
+  }
+  // every lane of the wave calls; `has`: this lane brings (o, e[])
+  __device__ __forceinline__ void push(float *gbase, int64_t sc, int nc, bool has, int o, const float (&e)[NC]) {
+    const unsigned long long m = __ballot(has);
+    const int cnt = __popcll(m);
+    if (cnt == 0) return;                      // wave-uniform
+    if (n + cnt > 63) flush(gbase, sc, nc);    // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    const int dest = (has ? n + rank : 63) << 2;
+    const bool mine = lane >= n && lane < n + cnt;
+    const int po = __builtin_amdgcn_ds_permute(dest, o);
+    off = mine ? po : off;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float pv = __int_as_float(__builtin_amdgcn_ds_permute(dest, __float_as_int(e[c])));
+      v[c] = mine ? pv : v[c];
+    }
+    n += cnt;
+  }
+};
 
 template <bool HAS_THETA, bool HAS_GX, bool C3>
 __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int tiles_x, int tiles_y) {
@@ -399,8 +447,25 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
   const bool okx = tx0 + lx < W;
   const int C = C3 ? 3 : a.C;
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // theta source: the base-grid coordinate of the column (two IEEE divisions for align_corners = False) and theta[0] * xs once
+  // per lane, the row's coordinate and theta[1] * ys once per block (LDS table, read as a broadcast).  The products enter the
+  // same additions in the same order as in sample_pos: bit-identical positions.
+  __shared__ float4 ytab[HAS_THETA ? TILE_H : 1];
+  float xs_l = 0.f, ax = 0.f, dx = 0.f, th2 = 0.f, th5 = 0.f;
+  if (HAS_THETA) {
+    const float *th = a.theta + (int64_t)n * 6;
+    if (threadIdx.x < TILE_H) {
+      const float ysr = base_coord_step(min(trow * TILE_H + (int)threadIdx.x, H - 1), H, a.stepy, ac);
+      ytab[threadIdx.x] = make_float4(__fmul_rn(th[1], ysr), __fmul_rn(th[4], ysr), ysr, 0.f);
+    }
+    xs_l = base_coord_step(x, W, a.stepx, ac);
+    ax = __fmul_rn(th[0], xs_l); dx = __fmul_rn(th[3], xs_l); th2 = th[2]; th5 = th[5];
+    __syncthreads();
+  }
   for (int c0 = 0; c0 < C; c0 += FWD_MAXC) {   // one pass for the reference's three-channel frames
     const int nc = min(FWD_MAXC, C - c0);
+    LeftoverQueue<FWD_MAXC> queue;
+    queue.init();
     // pending south-row pair of the previous pixel of this lane
     bool p_on = false, p_vw = false, p_ve = false;
     int p_r = 0, p_xi = 0;
@@ -413,7 +478,12 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
       const bool ok = okx & (yy < H);
       const int y = min(yy, H - 1), pix = y * W + x;
       float ix, iy, xs, ys;
-      sample_pos<HAS_THETA>(a.grid, a.theta, n, y, x, H, W, a.stepx, a.stepy, ac, ix, iy, xs, ys);
+      if (HAS_THETA) {
+        const float4 yt = ytab[min(ly * TILE_K + k, TILE_H - 1)];
+        xs = xs_l; ys = yt.z;
+        ix = unnormalise(__fadd_rn(__fadd_rn(ax, yt.x), th2), W, ac);
+        iy = unnormalise(__fadd_rn(__fadd_rn(dx, yt.y), th5), H, ac);
+      } else sample_pos<false>(a.grid, a.theta, n, y, x, H, W, a.stepx, a.stepy, ac, ix, iy, xs, ys);
       const Taps t = make_taps(ix, iy, H, W);
       float g[FWD_MAXC];
       TapVals tv[FWD_MAXC];
@@ -438,13 +508,14 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
         // the pending pair sits on source row p_r at columns p_xi, p_xi + 1: it merges into this pixel's north pair when that
         // is the same row and column (validity of the row and of the columns is then the same on both sides)
         const bool merge = p_on & ok & t.yn & cols & (t.yi == p_r) & (t.xi == p_xi);
-        if (__any(p_on & !merge)) emit_row_pair<FWD_MAXC>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on & !merge, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
+        if (__any(p_on & !merge)) emit_row_pair<FWD_MAXC, true>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on & !merge, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
 #pragma unroll
         for (int c = 0; c < FWD_MAXC; ++c) {
           n_w[c] += merge ? p_w[c] : 0.f;
           n_e[c] += merge ? p_e[c] : 0.f;
         }
-        emit_row_pair<FWD_MAXC>(gxb + c0 * a.gx_sc, a.gx_sc, W, ok & t.yn & cols, t.yi, t.xi, t.xw, t.xe, n_w, n_e, nc);
+        const bool left = emit_row_pair<FWD_MAXC, false>(gxb + c0 * a.gx_sc, a.gx_sc, W, ok & t.yn & cols, t.yi, t.xi, t.xw, t.xe, n_w, n_e, nc);
+        queue.push(gxb + c0 * a.gx_sc, a.gx_sc, nc, left, t.yi * W + t.xi + 1, n_e);
         p_on = ok & t.ys & cols; p_r = t.yi + 1; p_xi = t.xi; p_vw = t.xw; p_ve = t.xe;
 #pragma unroll
         for (int c = 0; c < FWD_MAXC; ++c) { p_w[c] = s_w[c]; p_e[c] = s_e[c]; }
@@ -459,7 +530,13 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
         else { o[0] += gix; o[1] += giy; }   // generic channel counts: later groups add to this lane's own earlier store
       }
     }
-    if (HAS_GX && __any(p_on)) emit_row_pair<FWD_MAXC>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
+    if (HAS_GX) {
+      if (__any(p_on)) {
+        const bool left = emit_row_pair<FWD_MAXC, false>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
+        queue.push(gxb + c0 * a.gx_sc, a.gx_sc, nc, left, p_r * W + p_xi + 1, p_e);
+      }
+      queue.flush(gxb + c0 * a.gx_sc, a.gx_sc, nc);
+    }
   }
   if (HAS_THETA && a.partial) {
 #pragma unroll
