@@ -184,6 +184,19 @@ int tcl_ctx_bwd(const float *g_p_in, const float *g_c_mask, const float *c_feats
                 int64_t B, int64_t C, int64_t R, int64_t h, int64_t w,
                 int variant, int normalize, void *workspace, size_t workspace_bytes, void *stream);
 
+/*   The one entry point that ALLOCATES NOTHING and needs no workspace.  It has no counterpart in the reference; it exists for
+ *   callers that cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that forbid
+ *   hipMalloc.  Same arguments, kernels and results as tcl_ctx_fwd (inference: the backward pass still needs tcl_ctx_fwd's
+ *   workspace), with the forward's scratch in a 4 MiB device array inside the library (one copy per GPU, held until the
+ *   process ends).  Shapes whose tcl_ctx_workspace_bytes exceeds 4 MiB return TCL_ERR_WORKSPACE (C4's 32 targets x 10
+ *   references at 30 x 53 need 2.7 MiB).  All calls on one GPU share that array: calls that overlap on one GPU (two streams,
+ *   two threads) race; serialise them.  The array's address is looked up on the first call on each device: make that call
+ *   outside graph capture. */
+int tcl_ctx_fwd_static(const float *c_feats, const float *v_t, const float *v_aligned,
+                       float *p_in, float *c_mask, float *c_match,
+                       int64_t B, int64_t C, int64_t R, int64_t h, int64_t w, int64_t H, int64_t W,
+                       int variant, int normalize, void *stream);
+
 /* A9  ref_importance.  Replaces add_match_border (models/cpn.py:23-36) / the ref_importance block of the
  *   complete variant (models/cpn.py:178-186) incl. add_border (:39-44) and the 3x3-cross dilation of
  *   ImageTransforms.dilatate (utils/transforms.py:87-105), without the host round trip.

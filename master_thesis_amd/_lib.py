@@ -40,6 +40,7 @@ SIGNATURES = {
     "tcl_masked_softmax_bwd": (_INT, [_P] * 4 + [_I64] * 4 + [_P]),
     "tcl_ctx_workspace_bytes": (_SZ, [_I64] * 5),
     "tcl_ctx_fwd": (_INT, [_P] * 6 + [_I64] * 7 + [_INT, _INT, _P, _SZ, _P]),
+    "tcl_ctx_fwd_static": (_INT, [_P] * 6 + [_I64] * 7 + [_INT, _INT, _P]),
     "tcl_ctx_bwd_workspace_bytes": (_SZ, [_I64] * 5),
     "tcl_ctx_bwd": (_INT, [_P] * 6 + [_I64] * 5 + [_INT, _INT, _P, _SZ, _P]),
     "tcl_ref_importance": (_INT, [_P] * 3 + [_I64] * 6 + [_INT, _P]),

@@ -15,6 +15,7 @@
 //             c_mask and the concatenated decoder input, written once
 // All of it is HBM-bound (0.5 flop/byte): coalesced along the pixel axis of the NCHW-like (B,C,R+1,h,w) layout.
 #include "tcl_common.h"
+#include <mutex>
 
 namespace tcl {
 
@@ -1023,6 +1024,52 @@ extern "C" int tcl_ctx_fwd(const float *c_feats, const float *v_t, const float *
 #undef TCL_CTX_SIM
 #undef TCL_CTX_AGG
   return check_launch("tcl_ctx_fwd");
+}
+
+// ------------------------------------------------------------------------------------------ the entry point that allocates nothing
+// tcl_ctx_fwd for callers that cannot hand over a workspace because they cannot allocate one (HIP graph capture, tight
+// serving loops): the forward's scratch (resized masks, bit fields, per-channel partial sums) lives in this file-scope device
+// array instead.  Every GPU the library runs on holds its own 4 MiB copy until the process ends.  In host code the array's
+// name is only a stand-in; its device address on the CURRENT device comes from hipGetSymbolAddress, looked up once per
+// device and kept.
+constexpr size_t kCtxStaticBytes = (size_t)4 << 20;
+static __device__ __align__(256) unsigned char scratch[kCtxStaticBytes];
+constexpr int kMaxDevices = 64;
+static void *g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mu;
+
+static int ctx_static_scratch(void **out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices)
+    return set_error(TCL_ERR_LAUNCH, "tcl_ctx_fwd_static: hipGetDevice failed or device index %d out of range (%s)", dev, hipGetErrorString(e));
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void *ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+      return set_error(TCL_ERR_LAUNCH, "tcl_ctx_fwd_static: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return TCL_OK;
+}
+
+extern "C" int tcl_ctx_fwd_static(const float *c_feats, const float *v_t, const float *v_aligned, float *p_in, float *c_mask, float *c_match,
+                                  int64_t B, int64_t C, int64_t R, int64_t h, int64_t w, int64_t H, int64_t W, int variant, int normalize,
+                                  void *stream) {
+  int rc = ctx_check("tcl_ctx_fwd_static", B, C, R, h, w, variant);
+  if (rc) return rc;
+  const size_t need = tcl_ctx_workspace_bytes(B, C, R, h, w);
+  TCL_REQUIRE(need <= kCtxStaticBytes, TCL_ERR_WORKSPACE,
+              "tcl_ctx_fwd_static: this shape needs %zu bytes of scratch, the static buffer holds %zu (use tcl_ctx_fwd with a workspace)", need,
+              kCtxStaticBytes);
+  void *ptr = nullptr;
+  rc = ctx_static_scratch(&ptr);
+  if (rc) return rc;
+  // every word of the scratch the kernels read is written earlier in the same call (no accumulation across calls, nothing
+  // that has to start at zero), so the previous call's contents need no clearing
+  return tcl_ctx_fwd(c_feats, v_t, v_aligned, p_in, c_mask, c_match, B, C, R, h, w, H, W, variant, normalize, ptr, kCtxStaticBytes, stream);
 }
 
 static int ctx_bwd_csplit(int64_t B, int64_t C, int64_t hw) {
