@@ -85,6 +85,10 @@ struct TapVals { F2U n, s; };
 template <bool W2>
 __device__ __forceinline__ TapVals fetch_taps(const float *plane, const Taps &t, int W) {
   TapVals v;
+#ifdef TCL_ABL_NOLOAD   // diagnostic side build: no gathers (values from the address bits)
+  v.n.a = __int_as_float(t.ya); v.n.b = __int_as_float(t.xa); v.s.a = __int_as_float(t.yb); v.s.b = 1.f;
+  return v;
+#endif
   if (W2) {
     // unsigned 32-bit offsets off the (wave-uniform) plane pointer: one scalar base + vector offset per load, no 64-bit VALU
     v.n = *reinterpret_cast<const F2U *>(plane + (unsigned)(t.ya * W + t.xa));
@@ -150,11 +154,30 @@ constexpr int FWD_MAXC = 3;             // channels whose taps are fetched toget
 // eight XCDs streaming through the same DRAM pages) and no data-dependent branches: hipcc drains every outstanding
 // load at a branch join, which costs a memory round trip (measured: 4.0 -> 4.9 TB/s on align_set at 256x256).
 // VMODE and C3 (C == 3, the reference's frames) are template parameters for the same reason.
+#ifndef TCL_WARP_FWD_ITERS
+#define TCL_WARP_FWD_ITERS 1
+#endif
+constexpr int FWD_ITERS = TCL_WARP_FWD_ITERS;   // consecutive 256-pixel chunks per workgroup; A/B: 2 / 4 / 8 are 13-20 % SLOWER on the
+                                                // affine warp and +-3 % on align_set: workgroup dispatch is not what bounds these kernels
+
+template <bool HAS_THETA, bool W2, int VMODE, bool C3>
+__device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chunk);
+
 template <bool HAS_THETA, bool W2, int VMODE, bool C3>
 __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
+  const int nchunk = (a.H * a.W + 255) >> 8;
+  int n, cgroup;
+  if (!warp_block((nchunk + FWD_ITERS - 1) / FWD_ITERS, a.gf, a.NB * a.NF, n, cgroup)) return;
+#pragma unroll 1
+  for (int it = 0; it < FWD_ITERS; ++it) {
+    const int chunk = cgroup * FWD_ITERS + it;
+    if (chunk < nchunk) warp_fwd_body<HAS_THETA, W2, VMODE, C3>(a, n, chunk);
+  }
+}
+
+template <bool HAS_THETA, bool W2, int VMODE, bool C3>
+__device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chunk) {
   const int H = a.H, W = a.W;
-  int n, chunk;
-  if (!warp_block((H * W + 255) >> 8, a.gf, a.NB * a.NF, n, chunk)) return;
   const int b = n / a.NF, f = n - b * a.NF;
   const int pix = chunk * 256 + threadIdx.x;   // flattened: every wave reads / writes 256 contiguous, aligned bytes per plane
   if (pix >= H * W) return;
@@ -607,7 +630,7 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
   WarpArgs a{x, x_sb, x_sf, x_sc, v, v_sb, v_sf, grid, theta, x_out, xo_sb, xo_sf, xo_sc, v_out, vo_sb, vo_sf,
              (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H), (int)gf};
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grd = warp_grid(cdiv(H * W, 256), a.gf, NB * NF), blk(256);
+  const dim3 grd = warp_grid(cdiv(cdiv(H * W, 256), FWD_ITERS), a.gf, NB * NF), blk(256);
   const bool c3 = x_out != nullptr && C == 3;
 #define TCL_LAUNCH_WARP(TH, W2, VM)                                                                  \
   do {                                                                                                \
