@@ -368,88 +368,89 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
 //     pixel are lane neighbours (east / west) and consecutive rows of one lane (north / south), so their contributions are
 //     summed in registers first: a lane keeps the SOUTH-row contributions of its pixel pending and adds them to the NORTH-row
 //     contributions of its next pixel when that one lands exactly one source row lower at the same column (otherwise the
-//     pending pair is flushed as it is), and lane l hands its east value to lane l+1's west one when they share an address.
-//     What leaves is ~(1 + 1/TILE_K) adds per source pixel and channel, lanes along a row.  Any flow is handled: where the
-//     merges do not apply the adds simply go out unmerged.
+//     pending pair is flushed as it is); east / west neighbours meet in emit_row_aligned, whose lanes own aligned source
+//     addresses.  What leaves is ~(1 + 1/TILE_K) adds per source pixel and channel in 64-byte aligned requests.  Any flow is
+//     handled: where the merges do not apply the adds simply go out unmerged.
 //   * the theta gradient: six block sums per 2048 pixels instead of per 256 (the reductions, not HBM, bound the small kernel).
 constexpr int TILE_W = 64, TILE_K = 8, TILE_H = 4 * TILE_K;
 
-// One row pair (row r, columns xi and xi + 1) of contributions per lane -> global atomics, after the east -> west hand-over
-// between neighbouring lanes.  `on`: this lane has a pair to emit; vw / ve: its west / east column lies inside the image.
-// Every lane of the wave must call (shuffles).  r and xi fit 14 bits here (H, W < 16384: checked by the host).
-// Returns whether this lane still holds an EAST value that no neighbour took (the caller queues it, see LeftoverQueue);
-// with DIRECT_EAST those are added here instead.
-template <int NC, bool DIRECT_EAST>
-__device__ __forceinline__ bool emit_row_pair(float *gbase, int64_t sc, int W, bool on, int r, int xi, bool vw, bool ve,
-                                              float (&w)[NC], float (&e)[NC], int nc) {
-  const int lane = threadIdx.x & 63;
-  const int key = on ? ((xi & 0x3fff) | ((r & 0x3fff) << 14)) : -1;
-  const int kx = on ? ((vw ? 1 : 0) | (ve ? 2 : 0)) : 0;
-  const int key_up = __shfl_up(key, 1, 64), kx_up = __shfl_up(kx, 1, 64);
-  const int key_dn = __shfl_down(key, 1, 64), kx_dn = __shfl_down(kx, 1, 64);
-  // pair (p, q = p + 1): same row, xi_q == xi_p + 1 (no wrap at 14 bits), east of p valid exactly when west of q is
-  auto pair_ok = [](int kp, int xp, int kq, int xq) {
-    return kp != -1 && kq != -1 && (kq - kp) == 1 && ((kp & 0x3fff) != 0x3fff) && (((xp >> 1) & 1) == (xq & 1));
-  };
-  const bool hand_east = lane < 63 && pair_ok(key, kx, key_dn, kx_dn);
-  const bool take_west = lane > 0 && pair_ok(key_up, kx_up, key, kx);
-  float *g = gbase + r * W + xi;
+__device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const float e_up = __shfl_up(e[c], 1, 64);
-    const float wv = take_west ? w[c] + e_up : w[c];
-    if (on && c < nc) {
-      if (vw) atomicAdd(g + c * sc, wv);
-      if (DIRECT_EAST && ve && !hand_east) atomicAdd(g + c * sc + 1, e[c]);
-    }
-  }
-  return on && ve && !hand_east;
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
 }
 
-// Leftover east values (the last lane's, and those at column gaps of an upscaling flow or at repeated columns of a
-// downscaling one) are few per row, but a float-atomic wave instruction costs the CU its ~50 ns whatever the number of active
-// lanes (MI355X_MICROARCH.md, Global float atomics: one wave instruction per ~50 ns per CU).  They are therefore compacted
-// into a wave-level queue held in registers, one slot per lane (slot 63 is the dump for lanes that have nothing to push), and
-// leave as one instruction per channel when the queue cannot take the next row's.
+// One row pair (source row r, columns xi and xi + 1) of contributions per lane -> global float atomics whose lanes OWN
+// consecutive, 64-byte aligned source addresses.
+//
+// Why: a float-atomic wave instruction leaves L2 as one memory-side request per 64-byte segment and per group of 16 lanes; the
+// chip retires ~20 G such requests per second (1.3 TB/s, MI355X_MICROARCH.md "Global float atomics"), and that rate is what
+// bounds this kernel (measured: 4.46 M requests per C3 launch = 9 per instruction when every lane adds at its own tap address:
+// 16 unaligned lanes always straddle two segments).  Here each lane pushes its west / east value to the lane that owns the
+// address (ds_permute: a lane-to-lane move, no LDS memory), the owner adds what it received, and ONE instruction per channel
+// adds 63 consecutive floats starting at a multiple of 16: four requests.  East / west neighbours meet in the owner's
+// sum, so no separate hand-over is needed.  Lanes whose address lies beyond the 63-float window take a second round with
+// a window of their own (rows of an upscaling or rotated flow); whatever is left after MAX_ROUNDS, and the losers of a push
+// collision (two lanes with the same tap: downscaling flows), add at their own address as before.  Any flow is handled.
+// Every lane of the wave must call.  `on`: this lane has a pair; vw / ve: its west / east column lies inside the image.
 template <int NC>
-struct LeftoverQueue {
-  int off;        // element offset of the slot's address from the channel-0 plane
-  float v[NC];
-  int n;          // slots in use (wave-uniform)
-  __device__ __forceinline__ void init() {
-    off = 0; n = 0;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) v[c] = 0.f;
-  }
-  __device__ __forceinline__ void flush(float *gbase, int64_t sc, int nc) {
-    const int lane = threadIdx.x & 63;
-    if (lane < n) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-        if (c < nc) atomicAdd(gbase + off + c * sc, v[c]);
-    }
-    n = 0;
-  }
-  // every lane of the wave calls; `has`: this lane brings (o, e[])
-  __device__ __forceinline__ void push(float *gbase, int64_t sc, int nc, bool has, int o, const float (&e)[NC]) {
-    const unsigned long long m = __ballot(has);
-    const int cnt = __popcll(m);
-    if (cnt == 0) return;                      // wave-uniform
-    if (n + cnt > 63) flush(gbase, sc, nc);    // wave-uniform
-    const int lane = threadIdx.x & 63;
-    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-    const int dest = (has ? n + rank : 63) << 2;
-    const bool mine = lane >= n && lane < n + cnt;
-    const int po = __builtin_amdgcn_ds_permute(dest, o);
-    off = mine ? po : off;
+__device__ __forceinline__ void emit_row_aligned(float *gbase, int64_t sc, int W, bool on, int r, int xi, bool vw, bool ve,
+                                                 float (&w)[NC], float (&e)[NC], int nc) {
+  constexpr int MAX_ROUNDS = 3;
+  const int lane = threadIdx.x & 63;
+  const int off = r * W + xi;   // offset of the west tap (-1 at r = 0, xi = -1: vw is false then)
+  bool todo = on & (vw | ve);
+  // Downscaling flows: two neighbouring lanes with the SAME tap.  The second lane of such a pair takes the first one's values
+  // (one pass: pairs only; the third lane of a longer run loses the push below and adds at its own address).
+  {
+    const int key = todo ? off : 0x7fffffff - lane;                  // distinct for idle lanes
+    const int k1 = __shfl_up(key, 1, 64), k2 = __shfl_up(key, 2, 64), kd = __shfl_down(key, 1, 64);
+    const bool take = todo & (lane >= 1) & (k1 == key) & ((lane < 2) | (k2 != key));   // lane - 1 heads a run that I continue
+    const bool give = todo & (lane < 63) & (kd == key) & ((lane < 1) | (k1 != key));   // I head a run and lane + 1 takes me
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const float pv = __int_as_float(__builtin_amdgcn_ds_permute(dest, __float_as_int(e[c])));
-      v[c] = mine ? pv : v[c];
+      const float w1 = __shfl_up(w[c], 1, 64), e1 = __shfl_up(e[c], 1, 64);
+      w[c] += take ? w1 : 0.f;
+      e[c] += take ? e1 : 0.f;
     }
-    n += cnt;
+    todo = todo & !give;
   }
-};
+#pragma unroll 1
+  for (int round = 0; round < MAX_ROUNDS && __any(todo); ++round) {
+    const int base = wave_min_i(todo ? off : 0x7fffffff) & ~15;
+    const int dw = off - base;
+    const bool part = todo & (dw <= 61);        // both taps inside lanes 0 .. 62 (lane 63 is the dump of the lanes that do not push)
+    const bool pw = part & vw, pe = part & ve;
+    const int aw = (pw ? dw : 63) << 2, ae = (pe ? dw + 1 : 63) << 2;
+    const int idw = __builtin_amdgcn_ds_permute(aw, lane + 1), ide = __builtin_amdgcn_ds_permute(ae, lane + 1);   // 0 = nobody pushed here
+    const bool lostw = pw & (__builtin_amdgcn_ds_bpermute(aw, idw) != lane + 1);   // another lane with the same tap won the slot
+    const bool loste = pe & (__builtin_amdgcn_ds_bpermute(ae, ide) != lane + 1);
+    const bool recv = (lane < 63) & ((idw | ide) != 0);
+    const bool any_lost = __any(lostw | loste);
+    float *g = gbase + base + lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float rw = __int_as_float(__builtin_amdgcn_ds_permute(aw, __float_as_int(w[c])));
+      const float re = __int_as_float(__builtin_amdgcn_ds_permute(ae, __float_as_int(e[c])));
+      if (c < nc) {
+        if (recv) atomicAdd(g + c * sc, (idw != 0 ? rw : 0.f) + (ide != 0 ? re : 0.f));
+        if (any_lost) {   // wave-uniform: no instruction at all in the common case
+          if (lostw) atomicAdd(gbase + off + c * sc, w[c]);
+          if (loste) atomicAdd(gbase + off + 1 + c * sc, e[c]);
+        }
+      }
+    }
+    todo = todo & !part;
+  }
+  if (__any(todo)) {   // wild flows: the remaining lanes add at their own addresses
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (todo && c < nc) {
+        if (vw) atomicAdd(gbase + off + c * sc, w[c]);
+        if (ve) atomicAdd(gbase + off + 1 + c * sc, e[c]);
+      }
+  }
+}
 
 template <bool HAS_THETA, bool HAS_GX, bool C3>
 __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int tiles_x, int tiles_y) {
@@ -487,8 +488,6 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
   }
   for (int c0 = 0; c0 < C; c0 += FWD_MAXC) {   // one pass for the reference's three-channel frames
     const int nc = min(FWD_MAXC, C - c0);
-    LeftoverQueue<FWD_MAXC> queue;
-    queue.init();
     // pending south-row pair of the previous pixel of this lane
     bool p_on = false, p_vw = false, p_ve = false;
     int p_r = 0, p_xi = 0;
@@ -531,14 +530,13 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
         // the pending pair sits on source row p_r at columns p_xi, p_xi + 1: it merges into this pixel's north pair when that
         // is the same row and column (validity of the row and of the columns is then the same on both sides)
         const bool merge = p_on & ok & t.yn & cols & (t.yi == p_r) & (t.xi == p_xi);
-        if (__any(p_on & !merge)) emit_row_pair<FWD_MAXC, true>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on & !merge, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
+        if (__any(p_on & !merge)) emit_row_aligned<FWD_MAXC>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on & !merge, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
 #pragma unroll
         for (int c = 0; c < FWD_MAXC; ++c) {
           n_w[c] += merge ? p_w[c] : 0.f;
           n_e[c] += merge ? p_e[c] : 0.f;
         }
-        const bool left = emit_row_pair<FWD_MAXC, false>(gxb + c0 * a.gx_sc, a.gx_sc, W, ok & t.yn & cols, t.yi, t.xi, t.xw, t.xe, n_w, n_e, nc);
-        queue.push(gxb + c0 * a.gx_sc, a.gx_sc, nc, left, t.yi * W + t.xi + 1, n_e);
+        emit_row_aligned<FWD_MAXC>(gxb + c0 * a.gx_sc, a.gx_sc, W, ok & t.yn & cols, t.yi, t.xi, t.xw, t.xe, n_w, n_e, nc);
         p_on = ok & t.ys & cols; p_r = t.yi + 1; p_xi = t.xi; p_vw = t.xw; p_ve = t.xe;
 #pragma unroll
         for (int c = 0; c < FWD_MAXC; ++c) { p_w[c] = s_w[c]; p_e[c] = s_e[c]; }
@@ -553,13 +551,7 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
         else { o[0] += gix; o[1] += giy; }   // generic channel counts: later groups add to this lane's own earlier store
       }
     }
-    if (HAS_GX) {
-      if (__any(p_on)) {
-        const bool left = emit_row_pair<FWD_MAXC, false>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
-        queue.push(gxb + c0 * a.gx_sc, a.gx_sc, nc, left, p_r * W + p_xi + 1, p_e);
-      }
-      queue.flush(gxb + c0 * a.gx_sc, a.gx_sc, nc);
-    }
+    if (HAS_GX && __any(p_on)) emit_row_aligned<FWD_MAXC>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
   }
   if (HAS_THETA && a.partial) {
 #pragma unroll
