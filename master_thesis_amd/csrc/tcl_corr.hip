@@ -714,6 +714,18 @@ struct TileLoaderH {
     }
   }
 
+  // Full tiles (see TileLoader): per-thread cursor, block-uniform strides, no bounds checks
+  __device__ __forceinline__ static const float *thread_base(const float *base, int64_t ld, int row0, int tid) {
+    if (KC) return base + (int64_t)(row0 + tid / (BKH / 4)) * ld + (tid % (BKH / 4)) * 4;
+    return base + (int64_t)(tid / (ROWS / 4)) * ld + row0 + (tid % (ROWS / 4)) * 4;
+  }
+  __device__ __forceinline__ static int64_t step(int64_t ld) { return KC ? (NT / (BKH / 4)) * ld : (NT / (ROWS / 4)) * ld; }
+  __device__ __forceinline__ static int64_t kstep(int64_t ld) { return KC ? BKH : BKH * ld; }
+  __device__ __forceinline__ void load_full(const float *p0, int64_t st) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const f32x4 *>(p0 + i * st);
+  }
+
   // img_hi / img_lo: the operand's LDS images (lo unused when NS == 1)
   __device__ __forceinline__ void store(__bf16 *img_hi, __bf16 *img_lo, int tid) const {
 #pragma unroll
@@ -753,7 +765,7 @@ __device__ __forceinline__ bf16x8 read_frag_h(const __bf16 *img, int row0, int k
   return f;
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int NS>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int NS, bool FULL = false>
 __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -791,16 +803,32 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
   const int ktiles = (g.K + BKH - 1) / BKH;
   const int total = ktiles * g.nseg;
 
-  la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
-  lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
+  // FULL: per-thread operand cursors, advanced by a block-uniform stride per k-tile (segment change: rewind + a_ss / b_ss)
+  const float *pa = FULL ? la.thread_base(Ab, g.a_ld, m0, tid) : nullptr;
+  const float *pb = FULL ? lb.thread_base(Bb, g.b_ld, n0, tid) : nullptr;
+  const int64_t a_st = la.step(g.a_ld), b_st = lb.step(g.b_ld), a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
+  int kt_next = 1;
+  if (FULL) { la.load_full(pa, a_st); lb.load_full(pb, b_st); }
+  else {
+    la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
+    lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
+  }
   for (int t = 0; t < total; ++t) {
     la.store(Ah, Al, tid);
     lb.store(Bh, Bl, tid);
     __syncthreads();
     if (t + 1 < total) {
-      const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
-      la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BKH, g.M, g.K, tid);
-      lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BKH, g.N, g.K, tid);
+      if (FULL) {
+        if (kt_next == ktiles) { kt_next = 0; pa += g.a_ss - (ktiles - 1) * a_k; pb += g.b_ss - (ktiles - 1) * b_k; }
+        else { pa += a_k; pb += b_k; }
+        ++kt_next;
+        la.load_full(pa, a_st);
+        lb.load_full(pb, b_st);
+      } else {
+        const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
+        la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BKH, g.M, g.K, tid);
+        lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BKH, g.N, g.K, tid);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < BKH / 16; ++ks) {
@@ -898,6 +926,13 @@ static int launch_gemm_bf16(GemmArgs g, int nsplit, hipStream_t s, const char *w
   TCL_REQUIRE(blocks > 0 && blocks < (1LL << 31), TCL_ERR_SHAPE, "%s: grid of %ld blocks", what, (long)blocks);
   const bool vec = gemm_vec_ok(g, A_KC, B_KC);
   const dim3 grd((unsigned)blocks), blk(WM * WN * 64);
+#ifndef TCL_GEMM_NO_FULL
+  if (vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BKH == 0) {   // full tiles: cursor loads, no predication
+    if (nsplit == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 2, true>), grd, blk, 0, s, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 1, true>), grd, blk, 0, s, g);
+    return check_launch(what);
+  }
+#endif
   if (nsplit == 2) {
     if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 2>), grd, blk, 0, s, g);
     else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, false, 2>), grd, blk, 0, s, g);

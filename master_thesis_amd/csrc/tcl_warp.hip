@@ -154,11 +154,14 @@ constexpr int FWD_MAXC = 3;             // channels whose taps are fetched toget
 // eight XCDs streaming through the same DRAM pages) and no data-dependent branches: hipcc drains every outstanding
 // load at a branch join, which costs a memory round trip (measured: 4.0 -> 4.9 TB/s on align_set at 256x256).
 // VMODE and C3 (C == 3, the reference's frames) are template parameters for the same reason.
-#ifndef TCL_WARP_FWD_ITERS
-#define TCL_WARP_FWD_ITERS 1
+// Consecutive 256-pixel chunks per workgroup.  Measured (C3 / C4, cold): with a grid source (align_set: 8 loads + 4 stores per
+// lane, ~90 vector instructions) two chunks per workgroup are 7 % faster than one (0.0664 vs 0.0718 ms: the waves are so short
+// that their launch shows), four and eight are not; with theta (240 vector instructions per pixel) two / four / eight are
+// 13-20 % SLOWER (the iterations of a wave do not overlap, and the kernel is bound by vector issue, not by dispatch).
+#ifndef TCL_WARP_FWD_ITERS_GRID
+#define TCL_WARP_FWD_ITERS_GRID 2
 #endif
-constexpr int FWD_ITERS = TCL_WARP_FWD_ITERS;   // consecutive 256-pixel chunks per workgroup; A/B: 2 / 4 / 8 are 13-20 % SLOWER on the
-                                                // affine warp and +-3 % on align_set: workgroup dispatch is not what bounds these kernels
+template <bool HAS_THETA> struct FwdIters { static constexpr int value = HAS_THETA ? 1 : TCL_WARP_FWD_ITERS_GRID; };
 
 template <bool HAS_THETA, bool W2, int VMODE, bool C3>
 __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chunk);
@@ -167,10 +170,11 @@ template <bool HAS_THETA, bool W2, int VMODE, bool C3>
 __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
   const int nchunk = (a.H * a.W + 255) >> 8;
   int n, cgroup;
-  if (!warp_block((nchunk + FWD_ITERS - 1) / FWD_ITERS, a.gf, a.NB * a.NF, n, cgroup)) return;
+  constexpr int ITERS = FwdIters<HAS_THETA>::value;
+  if (!warp_block((nchunk + ITERS - 1) / ITERS, a.gf, a.NB * a.NF, n, cgroup)) return;
 #pragma unroll 1
-  for (int it = 0; it < FWD_ITERS; ++it) {
-    const int chunk = cgroup * FWD_ITERS + it;
+  for (int it = 0; it < ITERS; ++it) {
+    const int chunk = cgroup * ITERS + it;
     if (chunk < nchunk) warp_fwd_body<HAS_THETA, W2, VMODE, C3>(a, n, chunk);
   }
 }
@@ -622,7 +626,7 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
   WarpArgs a{x, x_sb, x_sf, x_sc, v, v_sb, v_sf, grid, theta, x_out, xo_sb, xo_sf, xo_sc, v_out, vo_sb, vo_sf,
              (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H), (int)gf};
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grd = warp_grid(cdiv(cdiv(H * W, 256), FWD_ITERS), a.gf, NB * NF), blk(256);
+  const dim3 grd = warp_grid(cdiv(cdiv(H * W, 256), theta ? FwdIters<true>::value : FwdIters<false>::value), a.gf, NB * NF), blk(256);
   const bool c3 = x_out != nullptr && C == 3;
 #define TCL_LAUNCH_WARP(TH, W2, VM)                                                                  \
   do {                                                                                                \
@@ -700,7 +704,11 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
   } while (0)
   // images of at least one tile: the tiled kernel for the input gradient (LDS-staged scatter-add) and for the theta gradient
   // (one set of block sums per 2048 pixels); the grid-gradient-only case stays on the one-pixel-per-lane kernel
+#ifdef TCL_BWD_GRID_TILED   // A/B: the grid-gradient-only case on the tiled kernel too
+  const bool tiled = W >= TILE_W && H >= TILE_H && W < 16384 && H < 16384;
+#else
   const bool tiled = W >= TILE_W && H >= TILE_H && W < 16384 && H < 16384 && (g_x || theta);
+#endif
   int nblk = per;
   if (tiled) {
     const int tx = (int)cdiv(W, TILE_W), ty = (int)cdiv(H, TILE_H);
@@ -714,7 +722,8 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
     if (theta) {
       if (g_x) TCL_LAUNCH_WTILE(true, true);
       else TCL_LAUNCH_WTILE(true, false);
-    } else TCL_LAUNCH_WTILE(false, true);
+    } else if (g_x) TCL_LAUNCH_WTILE(false, true);
+    else TCL_LAUNCH_WTILE(false, false);
 #undef TCL_LAUNCH_WTILE
   } else if (theta) {
     if (g_x) TCL_LAUNCH_WBWD(true, true);
