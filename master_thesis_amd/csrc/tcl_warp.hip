@@ -456,6 +456,14 @@ __device__ __forceinline__ void emit_row_aligned(float *gbase, int64_t sc, int W
   }
 }
 
+struct BwdRow {   // one output row of a lane in the tiled backward: taps, cotangents and gathered values of a channel group
+  Taps t;
+  int pix;
+  bool ok;
+  float xs, ys, g[FWD_MAXC];
+  TapVals tv[FWD_MAXC];
+};
+
 template <bool HAS_THETA, bool HAS_GX, bool C3>
 __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int tiles_x, int tiles_y) {
   __shared__ float red[4][6];
@@ -498,33 +506,38 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
     float p_w[FWD_MAXC], p_e[FWD_MAXC];
 #pragma unroll
     for (int c = 0; c < FWD_MAXC; ++c) p_w[c] = p_e[c] = 0.f;
-#pragma unroll 2
-    for (int k = 0; k < TILE_K; ++k) {
+    // Software-pipelined by one row: the loads of row k+1 are issued BEFORE the atomics / stores of row k.  vmcnt counts loads,
+    // stores and atomics in issue order, so a wave that adds and then loads waits for its own atomics (which complete at the
+    // memory side, thousands of cycles under load) before it can use the next row's loads.
+    auto fetch = [&](int k, BwdRow &r) {
       const int yy = ty0 + k;   // wave-uniform
-      const bool ok = okx & (yy < H);
-      const int y = min(yy, H - 1), pix = y * W + x;
-      float ix, iy, xs, ys;
+      r.ok = okx & (yy < H);
+      const int y = min(yy, H - 1);
+      r.pix = y * W + x;
+      float ix, iy;
       if (HAS_THETA) {
         const float4 yt = ytab[min(ly * TILE_K + k, TILE_H - 1)];
-        xs = xs_l; ys = yt.z;
+        r.xs = xs_l; r.ys = yt.z;
         ix = unnormalise(__fadd_rn(__fadd_rn(ax, yt.x), th2), W, ac);
         iy = unnormalise(__fadd_rn(__fadd_rn(dx, yt.y), th5), H, ac);
-      } else sample_pos<false>(a.grid, a.theta, n, y, x, H, W, a.stepx, a.stepy, ac, ix, iy, xs, ys);
-      const Taps t = make_taps(ix, iy, H, W);
-      float g[FWD_MAXC];
-      TapVals tv[FWD_MAXC];
+      } else sample_pos<false>(a.grid, a.theta, n, y, x, H, W, a.stepx, a.stepy, ac, ix, iy, r.xs, r.ys);
+      r.t = make_taps(ix, iy, H, W);
 #pragma unroll
       for (int c = 0; c < FWD_MAXC; ++c) {
         const int cc = min(c0 + c, C - 1);
-        g[c] = gp[cc * a.go_sc + pix];
-        tv[c] = fetch_taps<true>(xp + cc * a.x_sc, t, W);
+        r.g[c] = gp[cc * a.go_sc + r.pix];
+        r.tv[c] = fetch_taps<true>(xp + cc * a.x_sc, r.t, W);
       }
+    };
+    auto process = [&](const BwdRow &r) {
+      const Taps &t = r.t;
+      const bool ok = r.ok;
       float gix = 0.f, giy = 0.f, n_w[FWD_MAXC], n_e[FWD_MAXC], s_w[FWD_MAXC], s_e[FWD_MAXC];
 #pragma unroll
       for (int c = 0; c < FWD_MAXC; ++c) {
         float vnw, vne, vsw, vse;
-        select_taps<true>(tv[c], t, vnw, vne, vsw, vse);
-        const float gc = (ok & (c < nc)) ? g[c] : 0.f;
+        select_taps<true>(r.tv[c], t, vnw, vne, vsw, vse);
+        const float gc = (ok & (c < nc)) ? r.g[c] : 0.f;
         gix += gc * ((vne - vnw) * t.sy + (vse - vsw) * t.ny);
         giy += gc * ((vsw - vnw) * t.ex + (vse - vne) * t.wx);
         n_w[c] = gc * t.nw; n_e[c] = gc * t.ne; s_w[c] = gc * t.sw; s_e[c] = gc * t.se;
@@ -547,13 +560,20 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
       }
       gix *= mx; giy *= my;
       if (HAS_THETA) {
-        if (ok) { acc[0] += gix * xs; acc[1] += gix * ys; acc[2] += gix; acc[3] += giy * xs; acc[4] += giy * ys; acc[5] += giy; }
+        if (ok) { acc[0] += gix * r.xs; acc[1] += gix * r.ys; acc[2] += gix; acc[3] += giy * r.xs; acc[4] += giy * r.ys; acc[5] += giy; }
       } else if (a.g_grid && ok) {
-        float *o = a.g_grid + ((int64_t)n * HW + pix) * 2;
+        float *o = a.g_grid + ((int64_t)n * HW + r.pix) * 2;
         if (C3) st_stream2(o, gix, giy);
         else if (c0 == 0) { o[0] = gix; o[1] = giy; }
         else { o[0] += gix; o[1] += giy; }   // generic channel counts: later groups add to this lane's own earlier store
       }
+    };
+    BwdRow row[2];
+    fetch(0, row[0]);
+#pragma unroll
+    for (int k = 0; k < TILE_K; ++k) {
+      if (k + 1 < TILE_K) fetch(k + 1, row[(k + 1) & 1]);   // rows past H: clamped loads, nothing emitted
+      process(row[k & 1]);
     }
     if (HAS_GX && __any(p_on)) emit_row_aligned<FWD_MAXC>(gxb + c0 * a.gx_sc, a.gx_sc, W, p_on, p_r, p_xi, p_vw, p_ve, p_w, p_e, nc);
   }
