@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the raw PMC passes (r1_c2_hbm_bytes_raw.json, r1_ops_hbm_bytes_raw.json).
+"""profiles/traffic.json from the raw PMC passes (r2_legs_hbm_bytes_raw.json; round 1: r1_c2_hbm_bytes_raw.json, r1_ops_hbm_bytes_raw.json).
 
 The raw files are what `profiles/microbench/pmc_bytes.sh` writes: per kernel, the average FETCH_SIZE and WRITE_SIZE (KiB) of two separate
-`rocprofv3 --pmc` passes over `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-variants` and
-`bench_ops.py --iters 2`.  hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE is doubled as
+`rocprofv3 --pmc` passes over `bench.py --legs-only corr,warp,c4` (round 2: the cache-cold, rotating-buffer launches of every leg;
+round 1 used `bench.py --steps 1 ...` and `bench_ops.py --iters 2`).  hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE is doubled as
 MI355X_MICROARCH.md prescribes for gfx950 (a 128-byte request is counted as 64 bytes; calibrated there for 16-byte-per-lane
 streaming loads, so for the 4- and 8-byte-per-lane loads of the streaming kernels it is an upper estimate).
 Algorithmic bytes are the figures of DESIGN.md section 4 for the benchmarked shapes.
@@ -18,28 +18,28 @@ HAT = 256 * 4096 * 4                           # one normalised operand of one p
 NPIX_C3, NPIX_C4 = 128 * 256 * 256, 320 * 240 * 424
 CF = 32 * 128 * 11 * 30 * 53 * 4               # c_feats at C4
 ROWS = [  # (label, raw file, kernel-name substring, algorithmic bytes per launch)
-    ("gemm_f32_fwd (C2, 16 pairs)", "c2", "gemm_f32_kernel<128, 128, 2, 2, false, false", 16 * (C2_PAIR + 2 * HAT)),
-    ("gemm_f32_bwd_d_a (C2)", "c2", "gemm_f32_kernel<256, 128, 4, 2, true, true", 16 * (C2_PAIR + 2 * HAT)),
-    ("gemm_f32_bwd_d_r (C2)", "c2", "gemm_f32_kernel<256, 128, 4, 2, true, false", 16 * (C2_PAIR + 2 * HAT)),
-    ("corr_normalise (one of two launches)", "c2", "corr_normalise_keep_kernel", 16 * 2 * HAT),
-    ("corr_normalise_bwd", "c2", "corr_normalise_bwd_keep_kernel", 16 * 3 * HAT),
-    ("warp_fwd align_set 256^2 x128 (C3)", "ops", "warp_fwd_kernel<false, true, 1, true>", NPIX_C3 * 40),
-    ("warp_bwd grad-grid 256^2 x128 (C3)", "ops", "warp_bwd_kernel<false, false, true, true>", NPIX_C3 * 40),
-    ("warp_bwd grad-grid + grad-input", "ops", "warp_bwd_kernel<false, true, true, true>", NPIX_C3 * 52),
-    ("warp_fwd affine 240x424 x320 (C4)", "ops", "warp_fwd_kernel<true, true, 2, true>", NPIX_C4 * 32),
-    ("ctx_sim (C4, 32 targets)", "ops", "ctx_sim_kernel", CF),
-    ("ctx_aggregate (C4)", "ops", "ctx_aggregate_kernel", CF + 32 * 257 * 30 * 53 * 4),
-    ("ctx_bwd_dmatch (C4)", "ops", "ctx_bwd_dmatch_kernel", CF),
-    ("ctx_bwd_feats (C4)", "ops", "ctx_bwd_feats_", 2 * CF + 32 * 257 * 30 * 53 * 4),
-    ("ref_importance (C4)", "ops", "ref_importance_kernel", 32 * 3 * 11 * 240 * 424 * 4),
-    ("masked_softmax fwd (C4 shape)", "ops", "masked_softmax_fwd_small_kernel", 32 * 128 * 10 * 30 * 53 * 8),
-    ("corr1x1 fwd (32,256,64,64)", "ops", "corr1x1_fwd_kernel", 2 * 32 * 256 * 4096 * 4),
+    ("gemm_f32_fwd (C2, 16 pairs)", "legs", "gemm_f32_kernel<128, 128, 2, 2, false, false", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_bf16x3_fwd (C2)", "legs", "gemm_bf16_kernel<128, 128, 2, 2, false, false, true, 2", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_bf16_fwd (C2)", "legs", "gemm_bf16_kernel<128, 128, 2, 2, false, false, true, 1", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_f32_bwd_d_a (C2)", "legs", "gemm_f32_kernel<256, 128, 4, 2, true, true", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_f32_bwd_d_r (C2)", "legs", "gemm_f32_kernel<256, 128, 4, 2, true, false", 16 * (C2_PAIR + 2 * HAT)),
+    ("corr_normalise (one of two launches)", "legs", "corr_normalise_keep_kernel", 16 * 2 * HAT),
+    ("corr_normalise_bwd", "legs", "corr_normalise_bwd_keep_kernel", 16 * 3 * HAT),
+    ("warp_fwd align_set 256^2 x128 (C3)", "legs", "warp_fwd_kernel<false, true, 1, true>", NPIX_C3 * 40),
+    ("warp_bwd grad-grid 256^2 x128 (C3)", "legs", "warp_bwd_kernel<false, false, true, true>", NPIX_C3 * 40),
+    ("warp_bwd grad-grid + grad-input (tiled)", "legs", "warp_bwd_tile_kernel<false, true, true>", NPIX_C3 * 52),
+    ("warp_fwd affine 240x424 x320 (C4)", "legs", "warp_fwd_kernel<true, true, 2, true>", NPIX_C4 * 32),
+    ("warp_bwd theta gradient (C4, tiled)", "legs", "warp_bwd_tile_kernel<true, false, true>", NPIX_C4 * 24),
+    ("ctx_sim (C4, 32 targets)", "legs", "ctx_sim_kernel", CF),
+    ("ctx_aggregate (C4)", "legs", "ctx_aggregate_kernel", CF + 32 * 257 * 30 * 53 * 4),
+    ("ctx_bwd_dmatch (C4)", "legs", "ctx_bwd_dmatch_kernel", CF),
+    ("ctx_bwd_feats (C4)", "legs", "ctx_bwd_feats_", 2 * CF + 32 * 257 * 30 * 53 * 4),
+    ("ref_importance (C4)", "legs", "ref_importance_kernel", 32 * 3 * 11 * 240 * 424 * 4),
 ]
 
 
 def main():
-    raw = {"c2": json.load(open(os.path.join(HERE, "r1_c2_hbm_bytes_raw.json"))),
-           "ops": json.load(open(os.path.join(HERE, "r1_ops_hbm_bytes_raw.json")))}
+    raw = {"legs": json.load(open(os.path.join(HERE, "r2_legs_hbm_bytes_raw.json")))}
     out = {"_method": __doc__.strip()}
     for label, src, needle, algo in ROWS:
         hit = [v for k, v in raw[src].items() if needle in k]
@@ -50,7 +50,7 @@ def main():
         out[label] = {"fetch_kib_raw": round(f, 1), "write_kib_raw": round(w, 1), "hbm_bytes_per_launch": hbm,
                       "algorithmic_bytes_per_launch": int(algo), "ratio": round(hbm / algo, 3)}
         if "grad-input" in label:
-            out[label]["note"] = "WRITE_SIZE counts every float atomic as a write"
+            out[label]["note"] = "WRITE_SIZE counts every float atomic request as a write (does not include the caller's memset of grad_x)"
     out["gemm_f32_fwd_bytes_per_launch"] = out["gemm_f32_fwd (C2, 16 pairs)"]["hbm_bytes_per_launch"]   # read by bench.py
     json.dump(out, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)
     for k, v in out.items():
