@@ -16,6 +16,7 @@
 // same permutation on both operands, so a k-contiguous operand is fetched from LDS with one ds_read_b128
 // per lane (rows padded to 36 floats: conflict-free) and an m-contiguous one with plain ds_read_b32.
 #include "tcl_common.h"
+#include <type_traits>
 
 namespace tcl {
 
@@ -402,134 +403,61 @@ __device__ __forceinline__ f32x4 read_frag(const float *lds, int row, int kbase)
   return v;
 }
 
-// D[m][n] (+)= sum_k A(m,k) B(n,k); block tile BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN).
-// EPI_STORE writes D; EPI_ARGMAX instead reduces every row of the tile to (max value, first column reaching it) and
-// writes that pair to g.D as float2 at [z][m][n-tile] (the volume itself never reaches HBM).
+// One BKT-deep k-tile of a wave's TM x TN MFMA blocks, both operands k-major in LDS ([k][rows], rows permuted as
+// TileLoader::store<PW> describes).  A fragment slice (one k per lane half) is TM + TN scalar LDS reads.  Software-pipelined
+// by hand: the reads of slice s+1 are issued BEFORE the TM*TN MFMAs of slice s, so the LDS latency hides under 256
+// cycles of MFMA.  (hipcc on its own sinks every read group next to its use: `ds_read; s_waitcnt lgkmcnt(0);
+// 4 x mfma`, which leaves the matrix pipe idle for the LDS round trip 16 times per k-tile.)  The
+// sched_group_barriers pin that order: the DS reads of the next slice, then the MFMAs of this one.
+#ifndef TCL_GEMM_ABL
+#define TCL_GEMM_ABL 0   // timing ablations of side builds (wrong results): 1 no barriers, 2 no LDS stores, 4 no global loads in the loop, 8 no LDS reads
+#endif
+template <int BM, int BN, int WM, int WN, int BKT>
+__device__ __forceinline__ void mma_ktile_kmajor(const float *As, const float *Bs, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wid, int lr, int lh) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NSL = BKT / 2;   // slices per k-tile
+    float a_cur[TM], b_cur[TN], a_nxt[TM], b_nxt[TN];
+    const float *ap = As + (lh * 4) * BM + (wid / WN) * 32 + lr, *bp = Bs + (lh * 4) * BN + (wid % WN) * 32 + lr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_cur[i] = (TCL_GEMM_ABL & 8) ? (float)(lr + i) : ap[i * (WM * 32)];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_cur[j] = (TCL_GEMM_ABL & 8) ? (float)(lh + j) : bp[j * (WN * 32)];
+    __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) / 2, 0);       // DS reads of slice 0
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+      if (sl + 1 < NSL) {
+        const int kk = ((sl + 1) >> 2) * 8 + ((sl + 1) & 3);   // k row of the next slice (this lane half adds lh * 4)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_nxt[i] = (TCL_GEMM_ABL & 8) ? a_cur[i] : ap[kk * BM + i * (WM * 32)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b_nxt[j] = (TCL_GEMM_ABL & 8) ? b_cur[j] : bp[kk * BN + j * (WN * 32)];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[j], a_cur[i], acc[i][j], 0, 0, 0);
+      if (sl + 1 < NSL) __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) / 2, 0);   // DS reads of slice sl+1
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                           // MFMAs of slice sl
+      if (sl + 1 < NSL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
+      }
+    }
+}
+
 enum { EPI_STORE = 0, EPI_ARGMAX = 1 };
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int EPI, bool FULL = false>
-__global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
+// Epilogue of the fp32 GEMM kernels (the k-loop has ended on a barrier: `smem`, SMEM floats, is free again).
+template <int BM, int BN, int WM, int WN, int EPI, bool FULL, int SMEM>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float *smem, const GemmArgs &g, unsigned z, int m0, int n0,
+                                              unsigned tn) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_LDS = A_KC ? BM * KC_LD : BK * BM;
-  constexpr int B_LDS = B_KC ? BN * KC_LD : BK * BN;
-  __shared__ __attribute__((aligned(16))) float smem[A_LDS + B_LDS];
-  float *As = smem, *Bs = smem + A_LDS;
-
-  // block -> (batch, m-tile, n-tile): XCD-contiguous chunks, grouped so that neighbours share operand panels
-  const unsigned per_batch = g.tiles_m * g.tiles_n;
-  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned z = lin / per_batch, local = lin - z * per_batch;
-  constexpr unsigned GROUP = 8;
-  const unsigned gw = GROUP * g.tiles_n;
-  const unsigned gid = local / gw, first_m = gid * GROUP;
-  const unsigned gsz = min((unsigned)g.tiles_m - first_m, GROUP);
-  const unsigned tm = first_m + (local % gw) % gsz, tn = (local % gw) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
   const int lr = lane & 31, lh = lane >> 5;
-
-  const float *Ab = g.A + (int64_t)(z / g.a_bdiv) * g.a_bs;
-  const float *Bb = g.B + (int64_t)z * g.b_bs;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  TileLoader<BM, NT, A_KC, VEC> la;
-  TileLoader<BN, NT, B_KC, VEC> lb;
-  const int ktiles = (g.K + BK - 1) / BK;
-  const int total = ktiles * g.nseg;
-
-  // FULL: per-thread operand cursors, advanced by a block-uniform stride per k-tile (segment change: rewind + a_ss / b_ss)
-  const float *pa = FULL ? la.thread_base(Ab, g.a_ld, m0, tid) : nullptr;
-  const float *pb = FULL ? lb.thread_base(Bb, g.b_ld, n0, tid) : nullptr;
-  const int64_t a_st = la.step(g.a_ld), b_st = lb.step(g.b_ld), a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
-  int kt_next = 1;
-  if (FULL) { la.load_full(pa, a_st); lb.load_full(pb, b_st); }
-  else {
-    la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
-    lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
-  }
-  constexpr bool PIPE = !A_KC && !B_KC;   // hand-pipelined fragment reads, permuted LDS rows
-  for (int t = 0; t < total; ++t) {
-    la.template store<PIPE ? WM : 0>(As, tid);
-    lb.template store<PIPE ? WN : 0>(Bs, tid);
-    __syncthreads();
-    if (t + 1 < total) {  // prefetch the next tile while this one is multiplied
-      if (FULL) {
-        if (kt_next == ktiles) { kt_next = 0; pa += g.a_ss - (ktiles - 1) * a_k; pb += g.b_ss - (ktiles - 1) * b_k; }
-        else { pa += a_k; pb += b_k; }
-        ++kt_next;
-        la.load_full(pa, a_st);
-        lb.load_full(pb, b_st);
-      } else {
-        const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
-        la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BK, g.M, g.K, tid);
-        lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BK, g.N, g.K, tid);
-      }
-    }
-    if (PIPE) {
-      // Both operands k-major: a fragment slice (one k per lane half) is TM + TN scalar LDS reads.  Software-pipelined by
-      // hand: the reads of slice s+1 are issued BEFORE the TM*TN MFMAs of slice s, so the LDS latency hides under 256
-      // cycles of MFMA.  (hipcc on its own sinks every read group next to its use: `ds_read; s_waitcnt lgkmcnt(0);
-      // 4 x mfma`, which leaves the matrix pipe idle for the LDS round trip 16 times per k-tile.)  The
-      // sched_group_barriers pin that order: the DS reads of the next slice, then the MFMAs of this one.
-      constexpr int NSL = BK / 2;   // slices per k-tile
-      float a_cur[TM], b_cur[TN], a_nxt[TM], b_nxt[TN];
-      const float *ap = As + (lh * 4) * BM + (wid / WN) * 32 + lr, *bp = Bs + (lh * 4) * BN + (wid % WN) * 32 + lr;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a_cur[i] = ap[i * (WM * 32)];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b_cur[j] = bp[j * (WN * 32)];
-      __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) / 2, 0);       // DS reads of slice 0
-#pragma unroll
-      for (int sl = 0; sl < NSL; ++sl) {
-        if (sl + 1 < NSL) {
-          const int kk = ((sl + 1) >> 2) * 8 + ((sl + 1) & 3);   // k row of the next slice (this lane half adds lh * 4)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a_nxt[i] = ap[kk * BM + i * (WM * 32)];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b_nxt[j] = bp[kk * BN + j * (WN * 32)];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[j], a_cur[i], acc[i][j], 0, 0, 0);
-        if (sl + 1 < NSL) __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) / 2, 0);   // DS reads of slice sl+1
-        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                           // MFMAs of slice sl
-        if (sl + 1 < NSL) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a_cur[i] = a_nxt[i];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
-        }
-      }
-    } else
-#pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_KC>(As, wm0 + i * 32 + lr, kg * 8 + lh * 4);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_KC>(Bs, wn0 + j * 32 + lr, kg * 8 + lh * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // transposed tile, see the epilogues
-    }
-    __syncthreads();
-  }
-
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The tiles were accumulated
   // transposed (B fragment as the MFMA's A operand): a lane holds ONE row m of D and, in register quad q, the four
   // consecutive columns n = 8 q + 4 (lane >> 5) + e.
@@ -538,7 +466,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
     // first maximum), one exchange with the other lane half and one LDS step across the WN waves of the row.
     // smem is free again (the loop ended on a barrier): [BM][WN] (value, column) pairs
     float2 *best = reinterpret_cast<float2 *>(smem);
-    static_assert(BM * WN * 2 <= A_LDS + B_LDS, "argmax scratch must fit the staging buffer");
+    static_assert(BM * WN * 2 <= SMEM, "argmax scratch must fit the staging buffer");
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float bv = -INFINITY;
@@ -576,14 +504,14 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
   // each register quad, four consecutive columns n -> one 16-byte store per quad instead of four 4-byte stores.
   float *Db = g.D + (int64_t)z * g.d_bs;
 #ifndef TCL_GEMM_DIRECT_EPI   // A/B switch: the direct epilogue below for every case
-  if (FULL && EPI == EPI_STORE && TM == 2 && TN == 2 && WM == 2 && WN == 2 && g.d_vec) {
+  constexpr int ELD = WN * 32 + 4;   // staging row (floats), padded
+  if (FULL && EPI == EPI_STORE && WM * 32 * ELD <= SMEM && g.d_vec) {
     // Full tiles: the accumulators go through LDS once so that every store instruction of a wave writes eight complete,
     // line-aligned 128-byte row segments (the direct path writes 32-byte pieces of 32 different rows per instruction), and
     // those leave as non-temporal stores (whole lines: nothing to merge in L2, and the operand panels stay there).
-    // One pass per (i, j): 64 rows x (2 x 32) columns = 16 KB, rows padded to 68 floats.  C2 forward: 1.205 -> 1.188 ms
-    // back to back (non-temporal stores of the direct path's 16-byte pieces had doubled the time of the bf16 variant).
-    constexpr int ELD = 68;
-    static_assert(64 * ELD <= A_LDS + B_LDS, "epilogue staging must fit the operand buffers");
+    // One pass per (i, j): the (i, j) 32 x 32 blocks of all WM x WN waves = WM*32 rows x (WN x 32) columns, rows padded by 4
+    // floats.  C2 forward: 1.205 -> 1.188 ms back to back (non-temporal stores of the direct path's 16-byte pieces had
+    // doubled the time of the bf16 variant).
     const int wm = wid / WN, wn = wid % WN;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -597,8 +525,8 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int idx = tid + NT * k, row = idx >> 4, c4 = idx & 15, seg = c4 >> 3, within = (c4 & 7) * 4;
+        for (int k = 0; k < 4; ++k) {   // WM*32 x WN*8 float4 over NT = WM*WN*64 threads
+          const int idx = tid + NT * k, row = idx / (WN * 8), c4 = idx % (WN * 8), seg = c4 >> 3, within = (c4 & 7) * 4;
           const f32x4 val = *reinterpret_cast<const f32x4 *>(smem + row * ELD + seg * 32 + within);
           const int m = m0 + (row >> 5) * (BM / WM) + i * 32 + (row & 31), n = n0 + seg * (BN / WN) + j * 32 + within;
           __builtin_nontemporal_store(val, reinterpret_cast<f32x4 *>(Db + (int64_t)m * g.d_ld + n));
@@ -629,6 +557,356 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+// D[m][n] (+)= sum_k A(m,k) B(n,k); block tile BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN).
+// EPI_STORE writes D; EPI_ARGMAX instead reduces every row of the tile to (max value, first column reaching it) and
+// writes that pair to g.D as float2 at [z][m][n-tile] (the volume itself never reaches HBM).
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int EPI, bool FULL = false>
+__global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_LDS = A_KC ? BM * KC_LD : BK * BM;
+  constexpr int B_LDS = B_KC ? BN * KC_LD : BK * BN;
+  __shared__ __attribute__((aligned(16))) float smem[A_LDS + B_LDS];
+  float *As = smem, *Bs = smem + A_LDS;
+
+  // block -> (batch, m-tile, n-tile): XCD-contiguous chunks, grouped so that neighbours share operand panels
+  const unsigned per_batch = g.tiles_m * g.tiles_n;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned z = lin / per_batch, local = lin - z * per_batch;
+  constexpr unsigned GROUP = 8;
+  const unsigned gw = GROUP * g.tiles_n;
+  const unsigned gid = local / gw, first_m = gid * GROUP;
+  const unsigned gsz = min((unsigned)g.tiles_m - first_m, GROUP);
+  const unsigned tm = first_m + (local % gw) % gsz, tn = (local % gw) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const float *Ab = g.A + (int64_t)(z / g.a_bdiv) * g.a_bs;
+  const float *Bb = g.B + (int64_t)z * g.b_bs;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#ifdef TCL_GEMM_STAGGER
+  if (FULL && EPI == EPI_STORE && blockIdx.x < 1024)
+    for (int i = 0; i < (int)(blockIdx.x >> 8) * TCL_GEMM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+  TileLoader<BM, NT, A_KC, VEC> la;
+  TileLoader<BN, NT, B_KC, VEC> lb;
+  const int ktiles = (g.K + BK - 1) / BK;
+  const int total = ktiles * g.nseg;
+
+  // FULL: per-thread operand cursors, advanced by a block-uniform stride per k-tile (segment change: rewind + a_ss / b_ss)
+  const float *pa = FULL ? la.thread_base(Ab, g.a_ld, m0, tid) : nullptr;
+  const float *pb = FULL ? lb.thread_base(Bb, g.b_ld, n0, tid) : nullptr;
+  const int64_t a_st = la.step(g.a_ld), b_st = lb.step(g.b_ld), a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
+  int kt_next = 1;
+  if (FULL) { la.load_full(pa, a_st); lb.load_full(pb, b_st); }
+  else {
+    la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
+    lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
+  }
+  constexpr bool PIPE = !A_KC && !B_KC;   // hand-pipelined fragment reads, permuted LDS rows
+  for (int t = 0; t < total; ++t) {
+    if (!(TCL_GEMM_ABL & 2) || t == 0) {
+      la.template store<PIPE ? WM : 0>(As, tid);
+      lb.template store<PIPE ? WN : 0>(Bs, tid);
+    }
+    if (!(TCL_GEMM_ABL & 1)) __syncthreads();
+    if (t + 1 < total && !(TCL_GEMM_ABL & 4)) {  // prefetch the next tile while this one is multiplied
+      if (FULL) {
+        if (kt_next == ktiles) { kt_next = 0; pa += g.a_ss - (ktiles - 1) * a_k; pb += g.b_ss - (ktiles - 1) * b_k; }
+        else { pa += a_k; pb += b_k; }
+        ++kt_next;
+        la.load_full(pa, a_st);
+        lb.load_full(pb, b_st);
+      } else {
+        const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
+        la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BK, g.M, g.K, tid);
+        lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BK, g.N, g.K, tid);
+      }
+    }
+    if (PIPE) {
+      mma_ktile_kmajor<BM, BN, WM, WN, BK>(As, Bs, acc, wid, lr, lh);
+    } else
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_KC>(As, wm0 + i * 32 + lr, kg * 8 + lh * 4);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_KC>(Bs, wn0 + j * 32 + lr, kg * 8 + lh * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // transposed tile, see the epilogues
+    }
+    if (!(TCL_GEMM_ABL & 1)) __syncthreads();
+  }
+
+  gemm_epilogue<BM, BN, WM, WN, EPI, FULL, A_LDS + B_LDS>(acc, smem, g, z, m0, n0, tn);
+}
+
+// ---- forward contraction, LDS-DMA staging.  Full tiles only, both operands k-major (M % BM == N % BN == K % BKT == 0, 16-byte
+// aligned rows).  `global_load_lds_dwordx4` writes every k-tile straight into one of NST LDS stages: no staging registers, no
+// ds_write pass, tile t + NST - 1 in flight while tile t is multiplied, ONE barrier per k-tile.  One wave instruction lays
+// 64 x 16 bytes = 256 consecutive floats of the [k][rows] image; the row permutation of TileLoader::store<PW> is applied on the
+// per-lane SOURCE address (the LDS side of an LDS-DMA is lane-linear).
+typedef __attribute__((address_space(3))) void *lds_vptr;
+typedef const __attribute__((address_space(1))) void *glb_cvptr;
+
+template <int ROWS, int PW, int NW, int BKT>
+struct DmaTile {
+  static constexpr int PIECES = BKT * ROWS / 256, PER_WAVE = PIECES / NW, KPP = 256 / ROWS;   // k rows per piece
+  static_assert(256 % ROWS == 0 && PIECES % NW == 0, "a k-tile must split into whole 1 KiB pieces per wave");
+  // this lane's source of piece j = 0 of k-tile 0; piece j lies j * jstep(ld) floats further, the next k-tile BKT * ld
+  __device__ __forceinline__ static const float *lane_base(const float *base, int64_t ld, int row0, int wid, int lane) {
+    const int f = lane * 4, k = wid * KPP + f / ROWS, pos = f % ROWS;
+    const int row = PW > 0 ? ((pos / 32) % PW) * (ROWS / PW) + (pos / (PW * 32)) * 32 + (pos & 31) : pos;
+    return base + (int64_t)k * ld + row0 + row;
+  }
+  __device__ __forceinline__ static int64_t jstep(int64_t ld) { return (int64_t)NW * KPP * ld; }
+  __device__ __forceinline__ static void issue(const float *src, int64_t js, float *stage, int wid) {
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j)
+      __builtin_amdgcn_global_load_lds((glb_cvptr)(src + j * js), (lds_vptr)(stage + (j * NW + wid) * 256), 16, 0, 0);
+  }
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, int BKT, int NST, int EPI>
+__global__ void __launch_bounds__(WM *WN * 64) gemm_f32_glds_kernel(GemmArgs g) {
+  constexpr int NW = WM * WN;
+  constexpr int STAGE = BKT * (BM + BN), SMEM = NST * STAGE;
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM];
+  typedef DmaTile<BM, WM, NW, BKT> DA;
+  typedef DmaTile<BN, WN, NW, BKT> DB;
+  constexpr int PER_TILE = DA::PER_WAVE + DB::PER_WAVE;   // LDS-DMA instructions per wave and k-tile
+
+  const unsigned per_batch = g.tiles_m * g.tiles_n;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned z = lin / per_batch, local = lin - z * per_batch;
+  constexpr unsigned GROUP = 8;
+  const unsigned gw = GROUP * g.tiles_n;
+  const unsigned gid = local / gw, first_m = gid * GROUP;
+  const unsigned gsz = min((unsigned)g.tiles_m - first_m, GROUP);
+  const unsigned tm = first_m + (local % gw) % gsz, tn = (local % gw) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[BM / WM / 32][BN / WN / 32];
+#pragma unroll
+  for (int i = 0; i < BM / WM / 32; ++i)
+#pragma unroll
+    for (int j = 0; j < BN / WN / 32; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float *pa = DA::lane_base(g.A + (int64_t)(z / g.a_bdiv) * g.a_bs, g.a_ld, m0, wid, lane);
+  const float *pb = DB::lane_base(g.B + (int64_t)z * g.b_bs, g.b_ld, n0, wid, lane);
+  const int64_t a_js = DA::jstep(g.a_ld), b_js = DB::jstep(g.b_ld), a_k = (int64_t)BKT * g.a_ld, b_k = (int64_t)BKT * g.b_ld;
+  const int total = g.K / BKT;
+
+  // prologue: tiles 0 .. NST-2 in flight
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < total) {
+      DA::issue(pa, a_js, smem + st * STAGE, wid);
+      DB::issue(pb, b_js, smem + st * STAGE + BKT * BM, wid);
+      pa += a_k; pb += b_k;
+    }
+  int rd = 0, wr = NST - 1;
+  for (int t = 0; t < total; ++t) {
+    // tile t has landed once every wave's DMAs for it have retired (the NST - 2 younger tiles may stay in flight) ...
+    if (t + NST - 2 < total) wait_vmcnt<(NST - 2) * PER_TILE>(); else wait_vmcnt<0>();
+    // ... and every wave is past its reads of the stage that tile t + NST - 1 overwrites (multiplied in iteration t - 1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + NST - 1 < total) {
+      DA::issue(pa, a_js, smem + wr * STAGE, wid);
+      DB::issue(pb, b_js, smem + wr * STAGE + BKT * BM, wid);
+      pa += a_k; pb += b_k;
+    }
+    mma_ktile_kmajor<BM, BN, WM, WN, BKT>(smem + rd * STAGE, smem + rd * STAGE + BKT * BM, acc, wid, lr, lh);
+    rd = rd + 1 == NST ? 0 : rd + 1;
+    wr = wr + 1 == NST ? 0 : wr + 1;
+  }
+  __syncthreads();
+  gemm_epilogue<BM, BN, WM, WN, EPI, true, SMEM>(acc, smem, g, z, m0, n0, tn);
+}
+
+// ---- long-K contraction (the two backward products): 256 x 256 block tile, 4 waves, each wave 128 x 128 = 4 x 4 MFMA blocks
+// (256 accumulators, in AGPRs), ONE wave per SIMD and one block per CU.  Against the 64 x 64 wave tiles above this halves the
+// LDS fragment traffic per MFMA; with nothing else resident on the SIMD, every latency is hidden inside the wave instead:
+//   * two LDS stages, ONE barrier per 32-deep k-tile, placed before the tile's last 8-deep group: by then every wave has its
+//     last fragments of this tile in registers and has written its share of the next tile, so after the barrier the last
+//     group's MFMAs run while the first fragments of the NEXT tile are read;
+//   * fragments of group g+1 are read during the 64 MFMAs of group g (two register sets);
+//   * the next tile's global loads (issued a whole k-tile earlier) are written to the other LDS stage during groups 0 and 1,
+//     and the loads of the tile after that are issued right behind them (one staging register set).
+// Full tiles only (M, N % 256 == 0, K % 32 == 0, 16-byte aligned rows); A is k-contiguous, B either.
+template <bool B_KC>
+__global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 2, NT = 256, TM = 4, TN = 4;
+  constexpr int A_LDS = BM * KC_LD, B_LDS = B_KC ? BN * KC_LD : BK * BN, STAGE = A_LDS + B_LDS;
+  extern __shared__ __attribute__((aligned(16))) float smem_wide[];
+  float *smem = smem_wide;
+
+  const unsigned per_batch = g.tiles_m * g.tiles_n;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned z = lin / per_batch, local = lin - z * per_batch;
+  const unsigned tm = local % g.tiles_m, tn = local / g.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TileLoader<BM, NT, true, true> la;
+  TileLoader<BN, NT, B_KC, true> lb;
+  const int ktiles = g.K / BK, total = ktiles * g.nseg;
+  const float *pa = la.thread_base(g.A + (int64_t)(z / g.a_bdiv) * g.a_bs, g.a_ld, m0, tid);
+  const float *pb = lb.thread_base(g.B + (int64_t)z * g.b_bs, g.b_ld, n0, tid);
+  const int64_t a_st = la.step(g.a_ld), b_st = lb.step(g.b_ld), a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
+  const int64_t a_seg = g.a_ss - (int64_t)(ktiles - 1) * a_k, b_seg = g.b_ss - (int64_t)(ktiles - 1) * b_k;
+  int kt = 0, issued = 0;   // k-tile (within its segment) and count of the tile the cursors point at
+  // moves the cursors to the next tile; past the last tile they stay (the extra loads re-read the last tile, nobody uses them)
+  auto advance = [&]() {   // branch-free: a branch here would split the MFMA stream of the k-loop into basic blocks
+    const bool more = issued + 1 < total, wrap = kt + 1 == ktiles;
+    issued += more ? 1 : 0;
+    kt = more ? (wrap ? 0 : kt + 1) : kt;
+    pa += more ? (wrap ? a_seg : a_k) : 0;
+    pb += more ? (wrap ? b_seg : b_k) : 0;
+  };
+
+  f32x4 af[2][TM], bf[2][TN];
+  auto read_group = [&](auto setc, const float *st, int kg) {
+    constexpr int set = decltype(setc)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[set][i] = read_frag<BM, true>(st, wm0 + i * 32 + lr, kg * 8 + lh * 4);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[set][j] = read_frag<BN, B_KC>(st + A_LDS, wn0 + j * 32 + lr, kg * 8 + lh * 4);
+  };
+  auto mma_group = [&](auto setc) {
+    constexpr int set = decltype(setc)::value;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[set][j][e], af[set][i][e], acc[i][j], 0, 0, 0);   // transposed tile, see gemm_epilogue
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // instruction order of one group = 64 MFMAs + NR fragment reads (+ 8 LDS writes + 8 global loads in groups 0 and 1)
+  constexpr int NR = B_KC ? 8 : 12;   // 4 + 4 ds_read_b128, or 4 ds_read_b128 + 8 ds_read2_b32
+  auto deal_staged = [&]() {   // LDS reads cannot move across the LDS writes (may alias, as far as hipcc knows): reads first
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 64 - 32 - 2 * NR, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto deal_reads = [&]() {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 64 - 4 * NR, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  la.load_full(pa, a_st); lb.load_full(pb, b_st);
+  advance();
+  la.template store<0>(smem, tid); lb.template store<0>(smem + A_LDS, tid);
+  la.load_full(pa, a_st); lb.load_full(pb, b_st);   // tile 1 (or tile 0 again)
+  advance();
+  __syncthreads();
+  read_group(S0{}, smem, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < total; ++t) {
+    const float *cur = smem + (t & 1) * STAGE;
+    float *nxt = smem + ((t + 1) & 1) * STAGE;
+    // group 0: fragments of group 1; this thread's share of the next tile's A image; loads of the tile after it.
+    // hipcc on its own lumps the fragment reads and the staging instructions between two MFMA runs (8 ds_read_b128 in a row
+    // take longer to issue than one MFMA runs).  The sched_group_barriers deal them out one at a time between pairs of MFMAs;
+    // the sched_barriers keep every group's instructions inside the group.
+    read_group(S1{}, cur, 1);
+    la.template store<0>(nxt, tid);
+    la.load_full(pa, a_st);
+    mma_group(S0{});
+    deal_staged();
+    // group 1: the B image likewise
+    read_group(S0{}, cur, 2);
+    lb.template store<0>(nxt + A_LDS, tid);
+    lb.load_full(pb, b_st);
+    mma_group(S1{});
+    deal_staged();
+    advance();
+    // group 2: the tile's last fragments
+    read_group(S1{}, cur, 3);
+    mma_group(S0{});
+    deal_reads();
+    __syncthreads();   // every wave: done reading `cur`, done writing `nxt`
+    read_group(S0{}, nxt, 0);
+    mma_group(S1{});
+    deal_reads();
+  }
+  __syncthreads();
+  gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, 2 * STAGE>(acc, smem, g, z, m0, n0, tn);
+}
+
+template <bool B_KC>
+static int launch_gemm_wide(GemmArgs g, hipStream_t s, const char *what) {
+  g.tiles_m = g.M / 256;
+  g.tiles_n = g.N / 256;
+  g.d_vec = aligned(g.D, 16) && g.d_ld % 4 == 0 && g.d_bs % 4 == 0;
+  const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
+  constexpr size_t lds = 2 * (256 * KC_LD + (B_KC ? 256 * KC_LD : BK * 256)) * sizeof(float);
+  const hipError_t e = hipFuncSetAttribute((const void *)gemm_f32_wide_kernel<B_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  TCL_REQUIRE(e == hipSuccess, TCL_ERR_LAUNCH, "%s: %zu bytes of LDS per block refused: %s", what, lds, hipGetErrorString(e));
+  hipLaunchKernelGGL((gemm_f32_wide_kernel<B_KC>), dim3((unsigned)blocks), dim3(256), lds, s, g);
+  return check_launch(what);
+}
+// the wide kernel wants whole 256 x 256 tiles, 16-byte aligned rows and enough tiles to give most CUs one
+static bool gemm_wide_ok(const GemmArgs &g, bool b_kc) {
+  const bool vec = aligned(g.A, 16) && aligned(g.B, 16) && g.a_ld % 4 == 0 && g.b_ld % 4 == 0 && g.a_bs % 4 == 0 && g.b_bs % 4 == 0 &&
+                   g.a_ss % 4 == 0 && g.b_ss % 4 == 0;
+  (void)b_kc;
+  return vec && g.M % 256 == 0 && g.N % 256 == 0 && g.K % BK == 0 && (int64_t)(g.M / 256) * (g.N / 256) * g.nbatch >= 128;
+}
+
+#ifndef TCL_GLDS_BK
+#define TCL_GLDS_BK 32
+#endif
+#ifndef TCL_GLDS_NST
+#define TCL_GLDS_NST 2
+#endif
+
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI = EPI_STORE>
 static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
   g.tiles_m = (int)cdiv(g.M, BM);
@@ -641,6 +919,12 @@ static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
                    g.b_bs % 4 == 0 && g.a_ss % 4 == 0 && g.b_ss % 4 == 0 && (A_KC ? g.K % 4 == 0 : g.M % 4 == 0) &&
                    (B_KC ? g.K % 4 == 0 : g.N % 4 == 0);
   const bool full = vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0;
+#ifdef TCL_GEMM_GLDS   // A/B switch: LDS-DMA staging for the forward contraction (measured: no gain)
+  if constexpr (!A_KC && !B_KC) if (full && g.nseg == 1 && g.K % TCL_GLDS_BK == 0) {
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, WM, WN, TCL_GLDS_BK, TCL_GLDS_NST, EPI>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
+    return check_launch(what);
+  }
+#endif
 #ifdef TCL_GEMM_NO_FULL
   if (false)
 #else
@@ -1172,7 +1456,10 @@ extern "C" int tcl_corr4d_contract(const void *fwd_workspace, float *out, int64_
   g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
   if (precision != TCL_PREC_F32)
     return launch_gemm_bf16<128, 128, 2, 2, false, false>(g, precision == TCL_PREC_BF16X3 ? 2 : 1, (hipStream_t)stream, "tcl_corr4d_contract(bf16 gemm)");
-  return launch_gemm<128, 128, 2, 2, false, false>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
+#ifndef TCL_FWD_TILE   // A/B switch: block tile of the forward contraction (BM, BN, WM, WN)
+#define TCL_FWD_TILE 128, 128, 2, 2
+#endif
+  return launch_gemm<TCL_FWD_TILE, false, false>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
 }
 
 constexpr int ARGMAX_BN = 128;
@@ -1245,6 +1532,9 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_bs = F * C * P; g.b_bs = F * P * P; g.d_bs = C * P;
     g.a_ss = C * P; g.b_ss = P * P; g.a_bdiv = 1; g.nbatch = (int)B;
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, true>(g, nsplit, s, "tcl_corr4d_bwd(d_a bf16 gemm)");
+#ifndef TCL_GEMM_NO_WIDE
+    else if (gemm_wide_ok(g, true)) rc = launch_gemm_wide<true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
+#endif
     else rc = launch_gemm<256, 128, 4, 2, true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
     if (rc) return rc;
     launch_normalise_bwd(s, x_t, v_t, d_a, w.n_t, g_x_t, B, (int)C, 1, P);
@@ -1260,6 +1550,9 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_bs = C * P; g.b_bs = P * P; g.d_bs = C * P;
     g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, false>(g, nsplit, s, "tcl_corr4d_bwd(d_r bf16 gemm)");
+#ifndef TCL_GEMM_NO_WIDE
+    else if (gemm_wide_ok(g, false)) rc = launch_gemm_wide<false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
+#endif
     else rc = launch_gemm<256, 128, 4, 2, true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
     if (rc) return rc;
     launch_normalise_bwd(s, x_r, v_r, d_r, w.n_r, g_x_r, B * F, (int)C, (int)F, P);
