@@ -188,15 +188,17 @@ def _legs_corr(dev, corr, add, lib, stream, sp):
     gt, gr = torch.empty_like(xt), torch.empty_like(xr)
     _lib.call("tcl_corr4d_fwd", _p(xt), _p(vt), _p(xr), _p(vr), _p(out), B, C, F, P, 0, _p(ws), ws.numel(), sp)
     flops = 2.0 * P * P * C * B * F            # 8.59 GFLOP per pair forward
-    ms = time_rotating([lambda: _lib.call("tcl_corr4d_contract", _p(ws), _p(out), B, C, F, P, 0, sp)], stream, rounds=20, warm=3)
+    # MFMA-bound legs: ~0.1 s of the same launch first, so that the timed launches run at the sustained clock the >= 1 s timed
+    # region of the step sees (the first ~20 ms after an idle gap run 10 % slower)
+    ms = time_rotating([lambda: _lib.call("tcl_corr4d_contract", _p(ws), _p(out), B, C, F, P, 0, sp)], stream, rounds=40, warm=80)
     add("corr_fwd_contraction", "gemm_f32_kernel<128,128,2,2> (tcl_corr4d_contract)", ms, flops=flops)
     for prec, name in ((2, "bf16x3"), (1, "bf16")):
         ms = time_rotating([lambda: _lib.call("tcl_corr4d_contract", _p(ws), _p(out), B, C, F, P, prec, sp)], stream, rounds=20, warm=3)
         add("corr_fwd_contraction_" + name, "gemm_bf16_kernel<128,128,2,2,NS=%d> (variant, not the headline)" % (2 if prec == 2 else 1), ms,
             nbytes=B * F * P * P * 4 + (B + B * F) * C * P * 4, note="bound by the store of the fp32 volume (1 GiB per launch)")
     ms = time_rotating([lambda: _lib.call("tcl_corr4d_bwd", _p(cot), _p(xt), _p(vt), _p(xr), _p(vr), _p(ws), _p(gt), _p(gr), B, C, F, P, 0,
-                                          _p(ws2), ws2.numel(), sp)], stream, rounds=10, warm=2)
-    add("corr_bwd", "2 x gemm_f32_kernel<256,128,4,2> + corr_normalise_bwd (tcl_corr4d_bwd)", ms, flops=2 * flops)
+                                          _p(ws2), ws2.numel(), sp)], stream, rounds=20, warm=40)
+    add("corr_bwd", "2 x gemm_f32_wide_kernel (256x256 tiles) + corr_normalise_bwd (tcl_corr4d_bwd)", ms, flops=2 * flops)
     del out, ws, ws2, gt, gr
 
 

@@ -749,28 +749,32 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_glds_kernel(GemmArgs g) 
   gemm_epilogue<BM, BN, WM, WN, EPI, true, SMEM>(acc, smem, g, z, m0, n0, tn);
 }
 
-// ---- long-K contraction (the two backward products): 256 x 256 block tile, 4 waves, each wave 128 x 128 = 4 x 4 MFMA blocks
-// (256 accumulators, in AGPRs), ONE wave per SIMD and one block per CU.  Against the 64 x 64 wave tiles above this halves the
-// LDS fragment traffic per MFMA; with nothing else resident on the SIMD, every latency is hidden inside the wave instead:
+// ---- wide contraction: 256 x 256 block tile, 4 waves, each wave 128 x 128 = 4 x 4 MFMA blocks (256 accumulators, in
+// AGPRs), ONE wave per SIMD and one block per CU.  Against the 64 x 64 wave tiles above this halves the LDS fragment traffic
+// per MFMA; with nothing else resident on the SIMD, every latency is hidden inside the wave instead:
 //   * two LDS stages, ONE barrier per 32-deep k-tile, placed before the tile's last 8-deep group: by then every wave has its
 //     last fragments of this tile in registers and has written its share of the next tile, so after the barrier the last
 //     group's MFMAs run while the first fragments of the NEXT tile are read;
 //   * fragments of group g+1 are read during the 64 MFMAs of group g (two register sets);
 //   * the next tile's global loads (issued a whole k-tile earlier) are written to the other LDS stage during groups 0 and 1,
 //     and the loads of the tile after that are issued right behind them (one staging register set).
-// Full tiles only (M, N % 256 == 0, K % 32 == 0, 16-byte aligned rows); A is k-contiguous, B either.
-template <bool B_KC>
+// PERSIST (the forward contraction: K = C is short, the 256 KB output tile is not): one block per CU walks over output tiles
+// blockIdx.x, + gridDim.x, ...; the k-loop runs on across tile boundaries (the next output tile's first k-tiles are staged
+// during the last k-tiles of this one), the accumulators leave through an LDS region of their own, and their stores drain
+// under the next tile's MFMAs.
+// Full tiles only (M, N % 256 == 0, K % 32 == 0, 16-byte aligned rows).
+template <bool A_KC, bool B_KC, bool PERSIST>
 __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 2, NT = 256, TM = 4, TN = 4;
-  constexpr int A_LDS = BM * KC_LD, B_LDS = B_KC ? BN * KC_LD : BK * BN, STAGE = A_LDS + B_LDS;
+  constexpr int A_LDS = A_KC ? BM * KC_LD : BK * BM, B_LDS = B_KC ? BN * KC_LD : BK * BN, STAGE = A_LDS + B_LDS;
+  constexpr int EPI_LDS = WM * 32 * (WN * 32 + 4);   // staging of gemm_epilogue's whole-line path
   extern __shared__ __attribute__((aligned(16))) float smem_wide[];
   float *smem = smem_wide;
 
-  const unsigned per_batch = g.tiles_m * g.tiles_n;
-  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned z = lin / per_batch, local = lin - z * per_batch;
-  const unsigned tm = local % g.tiles_m, tn = local / g.tiles_m;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const unsigned per_batch = g.tiles_m * g.tiles_n, ntiles = per_batch * g.nbatch;
+  // output tiles of this block: first, first + stride, ... (count of them)
+  const unsigned first = PERSIST ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x), stride = PERSIST ? gridDim.x : 1;
+  const int count = PERSIST ? (int)((ntiles - first + stride - 1) / stride) : 1;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
   const int lr = lane & 31, lh = lane >> 5;
@@ -783,18 +787,29 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  TileLoader<BM, NT, true, true> la;
+  TileLoader<BM, NT, A_KC, true> la;
   TileLoader<BN, NT, B_KC, true> lb;
-  const int ktiles = g.K / BK, total = ktiles * g.nseg;
-  const float *pa = la.thread_base(g.A + (int64_t)(z / g.a_bdiv) * g.a_bs, g.a_ld, m0, tid);
-  const float *pb = lb.thread_base(g.B + (int64_t)z * g.b_bs, g.b_ld, n0, tid);
+  const int ktiles = g.K / BK, per_tile = ktiles * g.nseg, total = per_tile * count;
   const int64_t a_st = la.step(g.a_ld), b_st = lb.step(g.b_ld), a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
   const int64_t a_seg = g.a_ss - (int64_t)(ktiles - 1) * a_k, b_seg = g.b_ss - (int64_t)(ktiles - 1) * b_k;
-  int kt = 0, issued = 0;   // k-tile (within its segment) and count of the tile the cursors point at
-  // moves the cursors to the next tile; past the last tile they stay (the extra loads re-read the last tile, nobody uses them)
-  auto advance = [&]() {   // branch-free: a branch here would split the MFMA stream of the k-loop into basic blocks
+  const float *pa, *pb;
+  auto tile_cursors = [&](unsigned lin) {
+    const unsigned z = lin / per_batch, local = lin - z * per_batch;
+    pa = la.thread_base(g.A + (int64_t)(z / g.a_bdiv) * g.a_bs, g.a_ld, (int)(local % g.tiles_m) * BM, tid);
+    pb = lb.thread_base(g.B + (int64_t)z * g.b_bs, g.b_ld, (int)(local / g.tiles_m) * BN, tid);
+  };
+  tile_cursors(first);
+  int kt = 0, in_tile = 0, issued = 0, tile_i = 0;   // the k-tile the cursors point at: within its segment / its output tile / overall
+  // moves the cursors to the next k-tile; past the last one they stay (the extra loads re-read it, nobody uses them)
+  auto advance = [&]() {
+    if (PERSIST && in_tile + 1 == per_tile) {   // (rare, block-uniform) on to the next output tile
+      if (tile_i + 1 < count) { ++tile_i; ++issued; kt = 0; in_tile = 0; tile_cursors(first + tile_i * stride); }
+      return;
+    }
+    // branch-free: a branch on the common path would split the MFMA stream of the k-loop into basic blocks
     const bool more = issued + 1 < total, wrap = kt + 1 == ktiles;
     issued += more ? 1 : 0;
+    in_tile += more ? 1 : 0;
     kt = more ? (wrap ? 0 : kt + 1) : kt;
     pa += more ? (wrap ? a_seg : a_k) : 0;
     pb += more ? (wrap ? b_seg : b_k) : 0;
@@ -804,7 +819,7 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
   auto read_group = [&](auto setc, const float *st, int kg) {
     constexpr int set = decltype(setc)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[set][i] = read_frag<BM, true>(st, wm0 + i * 32 + lr, kg * 8 + lh * 4);
+    for (int i = 0; i < TM; ++i) af[set][i] = read_frag<BM, A_KC>(st, wm0 + i * 32 + lr, kg * 8 + lh * 4);
 #pragma unroll
     for (int j = 0; j < TN; ++j) bf[set][j] = read_frag<BN, B_KC>(st + A_LDS, wn0 + j * 32 + lr, kg * 8 + lh * 4);
   };
@@ -821,82 +836,107 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   // instruction order of one group = 64 MFMAs + NR fragment reads (+ 8 LDS writes + 8 global loads in groups 0 and 1)
-  constexpr int NR = B_KC ? 8 : 12;   // 4 + 4 ds_read_b128, or 4 ds_read_b128 + 8 ds_read2_b32
+  constexpr int NR = (A_KC ? 4 : 8) + (B_KC ? 4 : 8);   // per operand: 4 ds_read_b128, or 8 ds_read2_b32
   auto deal_staged = [&]() {   // LDS reads cannot move across the LDS writes (may alias, as far as hipcc knows): reads first
 #pragma unroll
     for (int i = 0; i < NR; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NR > 8 ? 1 : 2, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 64 - 32 - 2 * NR, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 64 - 8 * (NR > 8 ? 3 : 4) - 2 * NR, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto deal_reads = [&]() {
 #pragma unroll
-    for (int i = 0; i < NR; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-    __builtin_amdgcn_sched_group_barrier(0x008, 64 - 4 * NR, 0);
+    for (int i = 0; i < NR; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, NR > 12 ? 3 : 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 64 - (NR > 12 ? 3 : 4) * NR, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
 
   la.load_full(pa, a_st); lb.load_full(pb, b_st);
   advance();
   la.template store<0>(smem, tid); lb.template store<0>(smem + A_LDS, tid);
-  la.load_full(pa, a_st); lb.load_full(pb, b_st);   // tile 1 (or tile 0 again)
+  la.load_full(pa, a_st); lb.load_full(pb, b_st);   // k-tile 1 (or 0 again)
   advance();
   __syncthreads();
   read_group(S0{}, smem, 0);
   __builtin_amdgcn_sched_barrier(0);
-  for (int t = 0; t < total; ++t) {
-    const float *cur = smem + (t & 1) * STAGE;
-    float *nxt = smem + ((t + 1) & 1) * STAGE;
-    // group 0: fragments of group 1; this thread's share of the next tile's A image; loads of the tile after it.
-    // hipcc on its own lumps the fragment reads and the staging instructions between two MFMA runs (8 ds_read_b128 in a row
-    // take longer to issue than one MFMA runs).  The sched_group_barriers deal them out one at a time between pairs of MFMAs;
-    // the sched_barriers keep every group's instructions inside the group.
-    read_group(S1{}, cur, 1);
-    la.template store<0>(nxt, tid);
-    la.load_full(pa, a_st);
-    mma_group(S0{});
-    deal_staged();
-    // group 1: the B image likewise
-    read_group(S0{}, cur, 2);
-    lb.template store<0>(nxt + A_LDS, tid);
-    lb.load_full(pb, b_st);
-    mma_group(S1{});
-    deal_staged();
-    advance();
-    // group 2: the tile's last fragments
-    read_group(S1{}, cur, 3);
-    mma_group(S0{});
-    deal_reads();
-    __syncthreads();   // every wave: done reading `cur`, done writing `nxt`
-    read_group(S0{}, nxt, 0);
-    mma_group(S1{});
-    deal_reads();
+  // two loops, so that the accumulators' way out is not part of the hot loop's register allocation: the inner one runs over
+  // the k-tiles of one output tile; the staging pipeline (cursors, LDS stage parity `t`) runs on across output tiles
+  int t = 0;
+  for (int tile_done = 0; tile_done < count; ++tile_done) {
+    for (int kk = 0; kk < per_tile; ++kk, ++t) {
+      const float *cur = smem + (t & 1) * STAGE;
+      float *nxt = smem + ((t + 1) & 1) * STAGE;
+      // group 0: fragments of group 1; this thread's share of the next k-tile's A image; loads of the k-tile after it.
+      // hipcc on its own lumps the fragment reads and the staging instructions between two MFMA runs (8 ds_read_b128 in a row
+      // take longer to issue than one MFMA runs).  The sched_group_barriers deal them out one at a time between pairs of MFMAs;
+      // the sched_barriers keep every group's instructions inside the group.
+      read_group(S1{}, cur, 1);
+      la.template store<0>(nxt, tid);
+      la.load_full(pa, a_st);
+      mma_group(S0{});
+      deal_staged();
+      // group 1: the B image likewise
+      read_group(S0{}, cur, 2);
+      lb.template store<0>(nxt + A_LDS, tid);
+      lb.load_full(pb, b_st);
+      mma_group(S1{});
+      deal_staged();
+      advance();
+      // group 2: the k-tile's last fragments
+      read_group(S1{}, cur, 3);
+      mma_group(S0{});
+      deal_reads();
+      __syncthreads();   // every wave: done reading `cur`, done writing `nxt`
+      read_group(S0{}, nxt, 0);
+      mma_group(S1{});
+      deal_reads();
+    }
+    if (PERSIST) {   // output tile complete: store it, start the next one from zero
+      const unsigned lin = first + tile_done * stride, z = lin / per_batch, local = lin - z * per_batch;
+      gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, EPI_LDS>(acc, smem + 2 * STAGE, g, z, (int)(local % g.tiles_m) * BM, (int)(local / g.tiles_m) * BN,
+                                                              local / g.tiles_m);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
   }
-  __syncthreads();
-  gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, 2 * STAGE>(acc, smem, g, z, m0, n0, tn);
+  if (!PERSIST) {
+    const unsigned z = first / per_batch, local = first - z * per_batch;
+    __syncthreads();
+    gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, 2 * STAGE>(acc, smem, g, z, (int)(local % g.tiles_m) * BM, (int)(local / g.tiles_m) * BN, local / g.tiles_m);
+  }
 }
 
-template <bool B_KC>
+template <bool A_KC, bool B_KC, bool PERSIST>
 static int launch_gemm_wide(GemmArgs g, hipStream_t s, const char *what) {
   g.tiles_m = g.M / 256;
   g.tiles_n = g.N / 256;
   g.d_vec = aligned(g.D, 16) && g.d_ld % 4 == 0 && g.d_bs % 4 == 0;
-  const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
-  constexpr size_t lds = 2 * (256 * KC_LD + (B_KC ? 256 * KC_LD : BK * 256)) * sizeof(float);
-  const hipError_t e = hipFuncSetAttribute((const void *)gemm_f32_wide_kernel<B_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
+  if (PERSIST) {
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    TCL_REQUIRE(e == hipSuccess && cus > 0, TCL_ERR_LAUNCH, "%s: cannot read the CU count: %s", what, hipGetErrorString(e));
+    if (blocks > cus) blocks = cus;
+  }
+  constexpr size_t lds = (2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) + (PERSIST ? 64 * 68 : 0)) * sizeof(float);
+  const hipError_t e = hipFuncSetAttribute((const void *)gemm_f32_wide_kernel<A_KC, B_KC, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   TCL_REQUIRE(e == hipSuccess, TCL_ERR_LAUNCH, "%s: %zu bytes of LDS per block refused: %s", what, lds, hipGetErrorString(e));
-  hipLaunchKernelGGL((gemm_f32_wide_kernel<B_KC>), dim3((unsigned)blocks), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_wide_kernel<A_KC, B_KC, PERSIST>), dim3((unsigned)blocks), dim3(256), lds, s, g);
   return check_launch(what);
 }
 // the wide kernel wants whole 256 x 256 tiles, 16-byte aligned rows and enough tiles to give most CUs one
-static bool gemm_wide_ok(const GemmArgs &g, bool b_kc) {
-  const bool vec = aligned(g.A, 16) && aligned(g.B, 16) && g.a_ld % 4 == 0 && g.b_ld % 4 == 0 && g.a_bs % 4 == 0 && g.b_bs % 4 == 0 &&
-                   g.a_ss % 4 == 0 && g.b_ss % 4 == 0;
-  (void)b_kc;
+static bool gemm_wide_ok(const GemmArgs &g) {
+  const bool vec = aligned(g.A, 16) && aligned(g.B, 16) && aligned(g.D, 16) && g.a_ld % 4 == 0 && g.b_ld % 4 == 0 && g.d_ld % 4 == 0 &&
+                   g.a_bs % 4 == 0 && g.b_bs % 4 == 0 && g.d_bs % 4 == 0 && g.a_ss % 4 == 0 && g.b_ss % 4 == 0;
   return vec && g.M % 256 == 0 && g.N % 256 == 0 && g.K % BK == 0 && (int64_t)(g.M / 256) * (g.N / 256) * g.nbatch >= 128;
 }
 
@@ -1459,6 +1499,9 @@ extern "C" int tcl_corr4d_contract(const void *fwd_workspace, float *out, int64_
 #ifndef TCL_FWD_TILE   // A/B switch: block tile of the forward contraction (BM, BN, WM, WN)
 #define TCL_FWD_TILE 128, 128, 2, 2
 #endif
+#ifdef TCL_GEMM_WIDE_FWD
+  if (gemm_wide_ok(g)) return launch_gemm_wide<false, false, true>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
+#endif
   return launch_gemm<TCL_FWD_TILE, false, false>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
 }
 
@@ -1533,7 +1576,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_ss = C * P; g.b_ss = P * P; g.a_bdiv = 1; g.nbatch = (int)B;
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, true>(g, nsplit, s, "tcl_corr4d_bwd(d_a bf16 gemm)");
 #ifndef TCL_GEMM_NO_WIDE
-    else if (gemm_wide_ok(g, true)) rc = launch_gemm_wide<true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
+    else if (gemm_wide_ok(g)) rc = launch_gemm_wide<true, true, false>(g, s, "tcl_corr4d_bwd(d_a gemm)");
 #endif
     else rc = launch_gemm<256, 128, 4, 2, true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
     if (rc) return rc;
@@ -1551,7 +1594,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, false>(g, nsplit, s, "tcl_corr4d_bwd(d_r bf16 gemm)");
 #ifndef TCL_GEMM_NO_WIDE
-    else if (gemm_wide_ok(g, false)) rc = launch_gemm_wide<false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
+    else if (gemm_wide_ok(g)) rc = launch_gemm_wide<true, false, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
 #endif
     else rc = launch_gemm<256, 128, 4, 2, true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
     if (rc) return rc;
