@@ -159,6 +159,12 @@ def _masks(rng, shape, p=0.9):
     (2, 37, 3, 9, 7, True),        # ragged everything (scalar staging path, partial tiles)
     (1, 256, 1, 64, 64, False),    # one pair of C2
     (1, 20, 2, 24, 20, True),      # P % 128 != 0 with vector loads
+    # >= 128 whole 256 x 256 tiles in the backward products: the wide kernel (gemm_f32_wide_kernel), which the small cases
+    # above never reach: two reference frames = two accumulated segments and 8 k-tiles per segment; 32 k-tiles and 4 column
+    # tiles; two row tiles (C = 512)
+    (128, 256, 2, 16, 16, True),
+    (32, 256, 1, 32, 32, False),
+    (16, 512, 1, 32, 32, True),
 ])
 def test_corr4d_vs_oracle(mods, B, C, F, H, W, masked):
     rng = np.random.default_rng(B * 1000 + C)
