@@ -11,6 +11,13 @@ through the C ABI:
   * `F.affine_grid(theta_inv)`                         -> tcl_affine_grid.
 
 `simulate_movement_batch` is the data-parallel form: B independent frames (one per training sequence) in one launch.
+
+GPU-only contract: the frame `x` must already be on the HIP device (the reference calls simulate_movement on CPU tensors
+inside its dataset; `install_dropin()` therefore does NOT replace the reference's `utils.movement`, and a CPU frame raises a
+TclError that says so).  Do not call this from forked DataLoader workers: a forked child cannot use the parent's HIP context;
+simulate the movement in the training process after the batch has been moved to the device (simulate_movement_batch).
+The matrix chain differs from the reference in one documented way: the inverses come from one batched float32
+`torch.linalg.inv` instead of per-matrix `np.linalg.inv` (same LAPACK routine; `tests/golden/movement.npz` pins the result).
 skimage is not needed: `AffineTransform(translation, scale, rotation).params` is restated from its published formula
 (the library is absent from this image, so that one matrix constructor is pinned by the formula, not by skimage).
 """
@@ -45,6 +52,9 @@ class MovementSimulator:
 
     def simulate_movement_batch(self, x, n, affine_matrices=None):
         """x (B,C,H,W) -> (y (B,C,n,H,W), flow_inv (B,n,H,W,2), [B lists of n (3,3) matrices])."""
+        if not x.is_cuda:
+            raise _lib.TclError("MovementSimulator runs on the GPU only: move the frame to the HIP device first (x.to('cuda')); for CPU "
+                                "tensors inside a DataLoader worker keep the reference's own utils.movement")
         b, c, h, w = x.size()
         if affine_matrices is None:
             affine_matrices = []

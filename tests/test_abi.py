@@ -141,3 +141,12 @@ def test_shipped_library_reads_no_environment_switches():
     for fn in os.listdir(csrc):
         if fn.endswith((".hip", ".h")):
             assert "getenv" not in open(os.path.join(csrc, fn)).read(), fn
+
+
+def test_movement_simulator_names_its_gpu_only_contract():
+    """a CPU frame must fail with an error that says what to do, before any kernel or library call."""
+    import torch
+    from master_thesis_amd import _lib
+    from master_thesis_amd.utils.movement import MovementSimulator
+    with pytest.raises(_lib.TclError, match="GPU only"):
+        MovementSimulator(10, 0.1, 0.1).simulate_movement(torch.zeros(3, 8, 8), 3)
