@@ -22,6 +22,7 @@ namespace tcl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------ normalise
 // x element (b,c,f,p) at ((b*C + c)*F + f)*P + p; v element (b,f,p); hat element ((b*F+f)*C + c)*P + p.
@@ -370,6 +371,24 @@ struct TileLoader {
   __device__ __forceinline__ void load_full(const float *p0, int64_t st) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const f32x4 *>(p0 + i * st);
+  }
+  // The same loads as `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen`: a descriptor on the operand's (row0, k-tile 0)
+  // element, loop-invariant per-thread 32-bit byte offsets, and the k-tile as a scalar byte offset: no vector address
+  // arithmetic per load (hipcc keeps `uniform pointer + zext(offset)` as a 64-bit vector add per load otherwise).
+  __device__ __forceinline__ static void thread_offsets(uint32_t (&off)[NV], int64_t ld, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      off[i] = KC ? (uint32_t)(((int64_t)(idx / (BK / 4)) * ld + (idx % (BK / 4)) * 4) * 4)
+                  : (uint32_t)(((int64_t)(idx / (ROWS / 4)) * ld + (idx % (ROWS / 4)) * 4) * 4);
+    }
+  }
+  __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rsrc, const uint32_t (&off)[NV], int soff) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off[i], soff, 0);
+      r[i] = __builtin_bit_cast(f32x4, v);
+    }
   }
 
   // PW > 0 (k-major tiles only): rows are stored permuted so that the 32-row MFMA blocks of ONE wave lie PW*32 floats
@@ -790,13 +809,20 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
   TileLoader<BM, NT, A_KC, true> la;
   TileLoader<BN, NT, B_KC, true> lb;
   const int ktiles = g.K / BK, per_tile = ktiles * g.nseg, total = per_tile * count;
-  const int64_t a_st = la.step(g.a_ld), b_st = lb.step(g.b_ld), a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
-  const int64_t a_seg = g.a_ss - (int64_t)(ktiles - 1) * a_k, b_seg = g.b_ss - (int64_t)(ktiles - 1) * b_k;
-  const float *pa, *pb;
+  // operand cursors: block-uniform origins of the k-tile to load next (scalar registers) + loop-invariant per-thread offsets
+  uint32_t a_off[la.NV], b_off[lb.NV];
+  la.thread_offsets(a_off, g.a_ld, tid);
+  lb.thread_offsets(b_off, g.b_ld, tid);
+  const int a_k = (int)(la.kstep(g.a_ld) * 4), b_k = (int)(lb.kstep(g.b_ld) * 4);   // bytes from one k-tile to the next
+  const int a_seg = (int)(g.a_ss * 4) - (ktiles - 1) * a_k, b_seg = (int)(g.b_ss * 4) - (ktiles - 1) * b_k;   // ... into the next segment
+  __amdgpu_buffer_rsrc_t ra, rb;
+  int sa = 0, sb = 0;   // scalar byte offsets of the k-tile to load next
   auto tile_cursors = [&](unsigned lin) {
     const unsigned z = lin / per_batch, local = lin - z * per_batch;
-    pa = la.thread_base(g.A + (int64_t)(z / g.a_bdiv) * g.a_bs, g.a_ld, (int)(local % g.tiles_m) * BM, tid);
-    pb = lb.thread_base(g.B + (int64_t)z * g.b_bs, g.b_ld, (int)(local / g.tiles_m) * BN, tid);
+    const int64_t m0 = (int64_t)(local % g.tiles_m) * BM, n0 = (int64_t)(local / g.tiles_m) * BN;
+    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A + (int64_t)(z / g.a_bdiv) * g.a_bs + (A_KC ? m0 * g.a_ld : m0)), 0, 0x7fffffff, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.B + (int64_t)z * g.b_bs + (B_KC ? n0 * g.b_ld : n0)), 0, 0x7fffffff, 0x00020000);
+    sa = 0; sb = 0;
   };
   tile_cursors(first);
   int kt = 0, in_tile = 0, issued = 0, tile_i = 0;   // the k-tile the cursors point at: within its segment / its output tile / overall
@@ -811,8 +837,8 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
     issued += more ? 1 : 0;
     in_tile += more ? 1 : 0;
     kt = more ? (wrap ? 0 : kt + 1) : kt;
-    pa += more ? (wrap ? a_seg : a_k) : 0;
-    pb += more ? (wrap ? b_seg : b_k) : 0;
+    sa += more ? (wrap ? a_seg : a_k) : 0;
+    sb += more ? (wrap ? b_seg : b_k) : 0;
   };
 
   f32x4 af[2][TM], bf[2][TN];
@@ -855,45 +881,51 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  la.load_full(pa, a_st); lb.load_full(pb, b_st);
+  la.load_buf(ra, a_off, sa); lb.load_buf(rb, b_off, sb);
   advance();
   la.template store<0>(smem, tid); lb.template store<0>(smem + A_LDS, tid);
-  la.load_full(pa, a_st); lb.load_full(pb, b_st);   // k-tile 1 (or 0 again)
+  la.load_buf(ra, a_off, sa); lb.load_buf(rb, b_off, sb);   // k-tile 1 (or 0 again)
   advance();
   __syncthreads();
   read_group(S0{}, smem, 0);
   __builtin_amdgcn_sched_barrier(0);
+  // one k-tile out of LDS stage PAR (compile-time: every LDS address of the loop is then a loop-invariant base + an immediate)
+  auto ktile = [&](auto par) {
+    constexpr int PAR = decltype(par)::value;
+    const float *cur = smem + PAR * STAGE;
+    float *nxt = smem + (1 - PAR) * STAGE;
+    // group 0: fragments of group 1; this thread's share of the next k-tile's A image; loads of the k-tile after it.
+    // hipcc on its own lumps the fragment reads and the staging instructions between two MFMA runs (8 ds_read_b128 in a row
+    // take longer to issue than one MFMA runs).  The sched_group_barriers deal them out one at a time between pairs of MFMAs;
+    // the sched_barriers keep every group's instructions inside the group.
+    read_group(S1{}, cur, 1);
+    la.template store<0>(nxt, tid);
+    la.load_buf(ra, a_off, sa);
+    mma_group(S0{});
+    deal_staged();
+    // group 1: the B image likewise
+    read_group(S0{}, cur, 2);
+    lb.template store<0>(nxt + A_LDS, tid);
+    lb.load_buf(rb, b_off, sb);
+    mma_group(S1{});
+    deal_staged();
+    advance();
+    // group 2: the k-tile's last fragments
+    read_group(S1{}, cur, 3);
+    mma_group(S0{});
+    deal_reads();
+    __syncthreads();   // every wave: done reading `cur`, done writing `nxt`
+    read_group(S0{}, nxt, 0);
+    mma_group(S1{});
+    deal_reads();
+  };
   // two loops, so that the accumulators' way out is not part of the hot loop's register allocation: the inner one runs over
-  // the k-tiles of one output tile; the staging pipeline (cursors, LDS stage parity `t`) runs on across output tiles
-  int t = 0;
+  // the k-tiles of one output tile (an even number: the launcher checks), two per trip; the staging pipeline (cursors, LDS
+  // stages) runs on across output tiles
   for (int tile_done = 0; tile_done < count; ++tile_done) {
-    for (int kk = 0; kk < per_tile; ++kk, ++t) {
-      const float *cur = smem + (t & 1) * STAGE;
-      float *nxt = smem + ((t + 1) & 1) * STAGE;
-      // group 0: fragments of group 1; this thread's share of the next k-tile's A image; loads of the k-tile after it.
-      // hipcc on its own lumps the fragment reads and the staging instructions between two MFMA runs (8 ds_read_b128 in a row
-      // take longer to issue than one MFMA runs).  The sched_group_barriers deal them out one at a time between pairs of MFMAs;
-      // the sched_barriers keep every group's instructions inside the group.
-      read_group(S1{}, cur, 1);
-      la.template store<0>(nxt, tid);
-      la.load_full(pa, a_st);
-      mma_group(S0{});
-      deal_staged();
-      // group 1: the B image likewise
-      read_group(S0{}, cur, 2);
-      lb.template store<0>(nxt + A_LDS, tid);
-      lb.load_full(pb, b_st);
-      mma_group(S1{});
-      deal_staged();
-      advance();
-      // group 2: the k-tile's last fragments
-      read_group(S1{}, cur, 3);
-      mma_group(S0{});
-      deal_reads();
-      __syncthreads();   // every wave: done reading `cur`, done writing `nxt`
-      read_group(S0{}, nxt, 0);
-      mma_group(S1{});
-      deal_reads();
+    for (int kk = 0; kk < per_tile; kk += 2) {
+      ktile(S0{});
+      ktile(S1{});
     }
     if (PERSIST) {   // output tile complete: store it, start the next one from zero
       const unsigned lin = first + tile_done * stride, z = lin / per_batch, local = lin - z * per_batch;
@@ -933,11 +965,15 @@ static int launch_gemm_wide(GemmArgs g, hipStream_t s, const char *what) {
   hipLaunchKernelGGL((gemm_f32_wide_kernel<A_KC, B_KC, PERSIST>), dim3((unsigned)blocks), dim3(256), lds, s, g);
   return check_launch(what);
 }
-// the wide kernel wants whole 256 x 256 tiles, 16-byte aligned rows and enough tiles to give most CUs one
+// the wide kernel wants whole 256 x 256 x 64 tiles, 16-byte aligned rows and enough tiles to give most CUs one
 static bool gemm_wide_ok(const GemmArgs &g) {
   const bool vec = aligned(g.A, 16) && aligned(g.B, 16) && aligned(g.D, 16) && g.a_ld % 4 == 0 && g.b_ld % 4 == 0 && g.d_ld % 4 == 0 &&
                    g.a_bs % 4 == 0 && g.b_bs % 4 == 0 && g.d_bs % 4 == 0 && g.a_ss % 4 == 0 && g.b_ss % 4 == 0;
-  return vec && g.M % 256 == 0 && g.N % 256 == 0 && g.K % BK == 0 && (int64_t)(g.M / 256) * (g.N / 256) * g.nbatch >= 128;
+  // K % 64: an even number of k-tiles per output tile (the k-loop is unrolled over the two LDS stages); the byte offsets of
+  // one output tile's operand panels (rows x ld, all segments) are kept in 31 bits (buffer loads: 32-bit voffset + soffset)
+  return vec && g.M % 256 == 0 && g.N % 256 == 0 && g.K % (2 * BK) == 0 && g.a_ld < (1 << 21) && g.b_ld < (1 << 21) &&
+         (int64_t)g.nseg * g.a_ss * 4 + 256 * g.a_ld * 4 < (1LL << 31) && (int64_t)g.nseg * g.b_ss * 4 + 256 * g.b_ld * 4 < (1LL << 31) &&
+         (int64_t)(g.M / 256) * (g.N / 256) * g.nbatch >= 128;
 }
 
 #ifndef TCL_GLDS_BK
@@ -1048,6 +1084,24 @@ struct TileLoaderH {
   __device__ __forceinline__ void load_full(const float *p0, int64_t st) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const f32x4 *>(p0 + i * st);
+  }
+  // The same loads as `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen`: a descriptor on the operand's (row0, k-tile 0)
+  // element, loop-invariant per-thread 32-bit byte offsets, and the k-tile as a scalar byte offset: no vector address
+  // arithmetic per load (hipcc keeps `uniform pointer + zext(offset)` as a 64-bit vector add per load otherwise).
+  __device__ __forceinline__ static void thread_offsets(uint32_t (&off)[NV], int64_t ld, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      off[i] = KC ? (uint32_t)(((int64_t)(idx / (BK / 4)) * ld + (idx % (BK / 4)) * 4) * 4)
+                  : (uint32_t)(((int64_t)(idx / (ROWS / 4)) * ld + (idx % (ROWS / 4)) * 4) * 4);
+    }
+  }
+  __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rsrc, const uint32_t (&off)[NV], int soff) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off[i], soff, 0);
+      r[i] = __builtin_bit_cast(f32x4, v);
+    }
   }
 
   // img_hi / img_lo: the operand's LDS images (lo unused when NS == 1)
