@@ -624,12 +624,29 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
   const int ktiles = (g.K + BK - 1) / BK;
   const int total = ktiles * g.nseg;
 
-  // FULL: per-thread operand cursors, advanced by a block-uniform stride per k-tile (segment change: rewind + a_ss / b_ss)
+  // FULL: operand cursors = a buffer descriptor on the block's (row0, k-tile 0) element + loop-invariant per-thread byte
+  // offsets + a scalar byte offset that moves from k-tile to k-tile (segment change: rewind + a_ss / b_ss): no vector address
+  // arithmetic per load.  (The launcher checks that these offsets fit 31 bits.)
+#ifdef TCL_GEMM_PTR_CURSORS   // A/B switch: the round-1 per-thread pointer cursors
+  constexpr bool BUF = false;
+#else
+  constexpr bool BUF = FULL;
+#endif
   const float *pa = FULL ? la.thread_base(Ab, g.a_ld, m0, tid) : nullptr;
   const float *pb = FULL ? lb.thread_base(Bb, g.b_ld, n0, tid) : nullptr;
   const int64_t a_st = la.step(g.a_ld), b_st = lb.step(g.b_ld), a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
+  uint32_t a_off[la.NV], b_off[lb.NV];
+  __amdgpu_buffer_rsrc_t ra, rb;
+  int sa = 0, sb = 0;
+  if (BUF) {
+    la.thread_offsets(a_off, g.a_ld, tid);
+    lb.thread_offsets(b_off, g.b_ld, tid);
+    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Ab + (A_KC ? (int64_t)m0 * g.a_ld : m0)), 0, 0x7fffffff, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Bb + (B_KC ? (int64_t)n0 * g.b_ld : n0)), 0, 0x7fffffff, 0x00020000);
+  }
   int kt_next = 1;
-  if (FULL) { la.load_full(pa, a_st); lb.load_full(pb, b_st); }
+  if (BUF) { la.load_buf(ra, a_off, 0); lb.load_buf(rb, b_off, 0); }
+  else if (FULL) { la.load_full(pa, a_st); lb.load_full(pb, b_st); }
   else {
     la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
     lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
@@ -642,7 +659,13 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
     }
     if (!(TCL_GEMM_ABL & 1)) __syncthreads();
     if (t + 1 < total && !(TCL_GEMM_ABL & 4)) {  // prefetch the next tile while this one is multiplied
-      if (FULL) {
+      if (BUF) {
+        if (kt_next == ktiles) { kt_next = 0; sa += (int)(g.a_ss - (ktiles - 1) * a_k) * 4; sb += (int)(g.b_ss - (ktiles - 1) * b_k) * 4; }
+        else { sa += (int)a_k * 4; sb += (int)b_k * 4; }
+        ++kt_next;
+        la.load_buf(ra, a_off, sa);
+        lb.load_buf(rb, b_off, sb);
+      } else if (FULL) {
         if (kt_next == ktiles) { kt_next = 0; pa += g.a_ss - (ktiles - 1) * a_k; pb += g.b_ss - (ktiles - 1) * b_k; }
         else { pa += a_k; pb += b_k; }
         ++kt_next;
@@ -994,7 +1017,10 @@ static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
   const bool vec = aligned(g.A, 16) && aligned(g.B, 16) && g.a_ld % 4 == 0 && g.b_ld % 4 == 0 && g.a_bs % 4 == 0 &&
                    g.b_bs % 4 == 0 && g.a_ss % 4 == 0 && g.b_ss % 4 == 0 && (A_KC ? g.K % 4 == 0 : g.M % 4 == 0) &&
                    (B_KC ? g.K % 4 == 0 : g.N % 4 == 0);
-  const bool full = vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0;
+  // full tiles; and the byte offsets of one block's operand panels (rows x ld, all segments) fit the 31 bits of its buffer loads
+  const bool full = vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 &&
+                    (int64_t)g.nseg * g.a_ss * 4 + (int64_t)(A_KC ? BM : g.K) * g.a_ld * 4 < (1LL << 31) &&
+                    (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? BN : g.K) * g.b_ld * 4 < (1LL << 31);
 #ifdef TCL_GEMM_GLDS   // A/B switch: LDS-DMA staging for the forward contraction (measured: no gain)
   if constexpr (!A_KC && !B_KC) if (full && g.nseg == 1 && g.K % TCL_GLDS_BK == 0) {
     hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, WM, WN, TCL_GLDS_BK, TCL_GLDS_NST, EPI>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
