@@ -431,7 +431,9 @@ __device__ __forceinline__ f32x4 read_frag(const float *lds, int row, int kbase)
 #ifndef TCL_GEMM_ABL
 #define TCL_GEMM_ABL 0   // timing ablations of side builds (wrong results): 1 no barriers, 2 no LDS stores, 4 no global loads in the loop, 8 no LDS reads
 #endif
-template <int BM, int BN, int WM, int WN, int BKT>
+// FIRST: the accumulators are undefined on entry; the first slice's MFMAs take an inline-constant zero as C (saves the 64
+// v_accvgpr_write of a zero fill: VALU instructions, which take issue slots from the MFMAs of the SIMD's other waves).
+template <int BM, int BN, int WM, int WN, int BKT, bool FIRST = false>
 __device__ __forceinline__ void mma_ktile_kmajor(const float *As, const float *Bs, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wid, int lr, int lh) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NSL = BKT / 2;   // slices per k-tile
@@ -454,7 +456,10 @@ __device__ __forceinline__ void mma_ktile_kmajor(const float *As, const float *B
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[j], a_cur[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[j], a_cur[i], FIRST && sl == 0 ? zero : acc[i][j], 0, 0, 0);
+        }
       if (sl + 1 < NSL) __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) / 2, 0);   // DS reads of slice sl+1
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                           // MFMAs of slice sl
       if (sl + 1 < NSL) {
@@ -531,7 +536,19 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
     // One pass per (i, j): the (i, j) 32 x 32 blocks of all WM x WN waves = WM*32 rows x (WN x 32) columns, rows padded by 4
     // floats.  C2 forward: 1.205 -> 1.188 ms back to back (non-temporal stores of the direct path's 16-byte pieces had
     // doubled the time of the bf16 variant).
+    // The stores are buffer stores: a descriptor on the tile's first element, four loop-invariant per-thread byte offsets and
+    // the pass (i, j) as a scalar offset, i.e. no vector address arithmetic (VALU instructions take issue slots from the MFMAs
+    // of the other waves on the SIMD; the launcher checks that a tile's byte offsets fit 31 bits).
     const int wm = wid / WN, wn = wid % WN;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(Db + (int64_t)m0 * g.d_ld + n0, 0, 0x7fffffff, 0x00020000);
+    const int d_ld4 = g.d_ld * 4;
+    int st_off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // WM*32 x WN*8 float4 over NT = WM*WN*64 threads
+      const int idx = tid + NT * k, row = idx / (WN * 8), c4 = idx % (WN * 8), seg = c4 >> 3, within = (c4 & 7) * 4;
+      st_off[k] = ((row >> 5) * (BM / WM) + (row & 31)) * d_ld4 + (seg * (BN / WN) + within) * 4;
+    }
+    const int rd_off = (tid / (WN * 8)) * ELD + ((tid % (WN * 8)) >> 3) * 32 + (tid % 8) * 4;   // this thread's float4 of readback k = 0
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -543,12 +560,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
           *reinterpret_cast<f32x4 *>(smem + (wm * 32 + lr) * ELD + wn * 32 + 8 * q + 4 * lh) = val;
         }
         __syncthreads();
+        const int pass_off = i * 32 * d_ld4 + j * 32 * 4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {   // WM*32 x WN*8 float4 over NT = WM*WN*64 threads
-          const int idx = tid + NT * k, row = idx / (WN * 8), c4 = idx % (WN * 8), seg = c4 >> 3, within = (c4 & 7) * 4;
-          const f32x4 val = *reinterpret_cast<const f32x4 *>(smem + row * ELD + seg * 32 + within);
-          const int m = m0 + (row >> 5) * (BM / WM) + i * 32 + (row & 31), n = n0 + seg * (BN / WN) + j * 32 + within;
-          __builtin_nontemporal_store(val, reinterpret_cast<f32x4 *>(Db + (int64_t)m * g.d_ld + n));
+        for (int k = 0; k < 4; ++k) {
+          const f32x4 val = *reinterpret_cast<const f32x4 *>(smem + rd_off + k * (NT / (WN * 8)) * ELD);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, st_off[k], pass_off, 2 /* nt */);
         }
       }
     return;
@@ -581,7 +597,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
 // writes that pair to g.D as float2 at [z][m][n-tile] (the volume itself never reaches HBM).
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int EPI, bool FULL = false>
-__global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
+__global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? 4 : 1)) gemm_f32_kernel(GemmArgs g) {   // full-tile store kernels: 4 waves per SIMD (<= 128 registers)
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_LDS = A_KC ? BM * KC_LD : BK * BM;
@@ -607,13 +623,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
   const float *Ab = g.A + (int64_t)(z / g.a_bdiv) * g.a_bs;
   const float *Bb = g.B + (int64_t)z * g.b_bs;
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc[TM][TN];   // defined by the first k-tile (see mma_ktile_kmajor<FIRST>)
 
 #ifdef TCL_GEMM_STAGGER
   if (FULL && EPI == EPI_STORE && blockIdx.x < 1024)
@@ -652,7 +662,8 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
     lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
   }
   constexpr bool PIPE = !A_KC && !B_KC;   // hand-pipelined fragment reads, permuted LDS rows
-  for (int t = 0; t < total; ++t) {
+  auto ktile = [&](auto firstc, int t) {
+    constexpr bool FIRST = decltype(firstc)::value;
     if (!(TCL_GEMM_ABL & 2) || t == 0) {
       la.template store<PIPE ? WM : 0>(As, tid);
       lb.template store<PIPE ? WN : 0>(Bs, tid);
@@ -678,7 +689,7 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
       }
     }
     if (PIPE) {
-      mma_ktile_kmajor<BM, BN, WM, WN, BK>(As, Bs, acc, wid, lr, lh);
+      mma_ktile_kmajor<BM, BN, WM, WN, BK, FIRST>(As, Bs, acc, wid, lr, lh);
     } else
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
@@ -693,10 +704,15 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // transposed tile, see the epilogues
+          {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], FIRST && kg == 0 && e == 0 ? zero : acc[i][j], 0, 0, 0);   // transposed tile, see the epilogues
+          }
     }
     if (!(TCL_GEMM_ABL & 1)) __syncthreads();
-  }
+  };
+  ktile(std::true_type{}, 0);   // peeled: its MFMAs start from an inline zero
+  for (int t = 1; t < total; ++t) ktile(std::false_type{}, t);
 
   gemm_epilogue<BM, BN, WM, WN, EPI, FULL, A_LDS + B_LDS>(acc, smem, g, z, m0, n0, tn);
 }
@@ -996,7 +1012,7 @@ static bool gemm_wide_ok(const GemmArgs &g) {
   // one output tile's operand panels (rows x ld, all segments) are kept in 31 bits (buffer loads: 32-bit voffset + soffset)
   return vec && g.M % 256 == 0 && g.N % 256 == 0 && g.K % (2 * BK) == 0 && g.a_ld < (1 << 21) && g.b_ld < (1 << 21) &&
          (int64_t)g.nseg * g.a_ss * 4 + 256 * g.a_ld * 4 < (1LL << 31) && (int64_t)g.nseg * g.b_ss * 4 + 256 * g.b_ld * 4 < (1LL << 31) &&
-         (int64_t)(g.M / 256) * (g.N / 256) * g.nbatch >= 128;
+         (int64_t)256 * g.d_ld * 4 < (1LL << 31) && (int64_t)(g.M / 256) * (g.N / 256) * g.nbatch >= 128;
 }
 
 #ifndef TCL_GLDS_BK
@@ -1020,7 +1036,7 @@ static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
   // full tiles; and the byte offsets of one block's operand panels (rows x ld, all segments) fit the 31 bits of its buffer loads
   const bool full = vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 &&
                     (int64_t)g.nseg * g.a_ss * 4 + (int64_t)(A_KC ? BM : g.K) * g.a_ld * 4 < (1LL << 31) &&
-                    (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? BN : g.K) * g.b_ld * 4 < (1LL << 31);
+                    (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? BN : g.K) * g.b_ld * 4 < (1LL << 31) && (int64_t)BM * g.d_ld * 4 < (1LL << 31);
 #ifdef TCL_GEMM_GLDS   // A/B switch: LDS-DMA staging for the forward contraction (measured: no gain)
   if constexpr (!A_KC && !B_KC) if (full && g.nseg == 1 && g.K % TCL_GLDS_BK == 0) {
     hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, WM, WN, TCL_GLDS_BK, TCL_GLDS_NST, EPI>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
