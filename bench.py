@@ -191,7 +191,7 @@ def _legs_corr(dev, corr, add, lib, stream, sp):
     # MFMA-bound legs: ~0.1 s of the same launch first, so that the timed launches run at the sustained clock the >= 1 s timed
     # region of the step sees (the first ~20 ms after an idle gap run 10 % slower)
     ms = time_rotating([lambda: _lib.call("tcl_corr4d_contract", _p(ws), _p(out), B, C, F, P, 0, sp)], stream, rounds=40, warm=80)
-    add("corr_fwd_contraction", "gemm_f32_kernel<128,128,2,2> (tcl_corr4d_contract)", ms, flops=flops)
+    add("corr_fwd_contraction", "gemm_f32_kernel<128,128,2,2,...,FULL> (tcl_corr4d_contract)", ms, flops=flops)
     for prec, name in ((2, "bf16x3"), (1, "bf16")):
         ms = time_rotating([lambda: _lib.call("tcl_corr4d_contract", _p(ws), _p(out), B, C, F, P, prec, sp)], stream, rounds=20, warm=3)
         add("corr_fwd_contraction_" + name, "gemm_bf16_kernel<128,128,2,2,NS=%d> (variant, not the headline)" % (2 if prec == 2 else 1), ms,

@@ -376,12 +376,11 @@ struct TileLoader {
   // element, loop-invariant per-thread 32-bit byte offsets, and the k-tile as a scalar byte offset: no vector address
   // arithmetic per load (hipcc keeps `uniform pointer + zext(offset)` as a 64-bit vector add per load otherwise).
   __device__ __forceinline__ static void thread_offsets(uint32_t (&off)[NV], int64_t ld, int tid) {
+    // 32-bit arithmetic, one multiply: float4 i lies a block-uniform step(ld) floats behind float4 i - 1
+    const uint32_t ld4 = (uint32_t)ld * 4u, st4 = (uint32_t)step(ld) * 4u;
+    off[0] = KC ? (uint32_t)(tid / (BK / 4)) * ld4 + (uint32_t)(tid % (BK / 4)) * 16u : (uint32_t)(tid / (ROWS / 4)) * ld4 + (uint32_t)(tid % (ROWS / 4)) * 16u;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * NT;
-      off[i] = KC ? (uint32_t)(((int64_t)(idx / (BK / 4)) * ld + (idx % (BK / 4)) * 4) * 4)
-                  : (uint32_t)(((int64_t)(idx / (ROWS / 4)) * ld + (idx % (ROWS / 4)) * 4) * 4);
-    }
+    for (int i = 1; i < NV; ++i) off[i] = off[i - 1] + st4;
   }
   __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rsrc, const uint32_t (&off)[NV], int soff) {
 #pragma unroll
@@ -1131,12 +1130,11 @@ struct TileLoaderH {
   // element, loop-invariant per-thread 32-bit byte offsets, and the k-tile as a scalar byte offset: no vector address
   // arithmetic per load (hipcc keeps `uniform pointer + zext(offset)` as a 64-bit vector add per load otherwise).
   __device__ __forceinline__ static void thread_offsets(uint32_t (&off)[NV], int64_t ld, int tid) {
+    // 32-bit arithmetic, one multiply: float4 i lies a block-uniform step(ld) floats behind float4 i - 1
+    const uint32_t ld4 = (uint32_t)ld * 4u, st4 = (uint32_t)step(ld) * 4u;
+    off[0] = KC ? (uint32_t)(tid / (BK / 4)) * ld4 + (uint32_t)(tid % (BK / 4)) * 16u : (uint32_t)(tid / (ROWS / 4)) * ld4 + (uint32_t)(tid % (ROWS / 4)) * 16u;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * NT;
-      off[i] = KC ? (uint32_t)(((int64_t)(idx / (BK / 4)) * ld + (idx % (BK / 4)) * 4) * 4)
-                  : (uint32_t)(((int64_t)(idx / (ROWS / 4)) * ld + (idx % (ROWS / 4)) * 4) * 4);
-    }
+    for (int i = 1; i < NV; ++i) off[i] = off[i - 1] + st4;
   }
   __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rsrc, const uint32_t (&off)[NV], int soff) {
 #pragma unroll
