@@ -21,8 +21,10 @@ ROWS = [  # (label, raw file, kernel-name substring, algorithmic bytes per launc
     ("gemm_f32_fwd (C2, 16 pairs)", "legs", "gemm_f32_kernel<128, 128, 2, 2, false, false", 16 * (C2_PAIR + 2 * HAT)),
     ("gemm_bf16x3_fwd (C2)", "legs", "gemm_bf16_kernel<128, 128, 2, 2, false, false, true, 2", 16 * (C2_PAIR + 2 * HAT)),
     ("gemm_bf16_fwd (C2)", "legs", "gemm_bf16_kernel<128, 128, 2, 2, false, false, true, 1", 16 * (C2_PAIR + 2 * HAT)),
-    ("gemm_f32_bwd_d_a (C2)", "legs", "gemm_f32_kernel<256, 128, 4, 2, true, true", 16 * (C2_PAIR + 2 * HAT)),
-    ("gemm_f32_bwd_d_r (C2)", "legs", "gemm_f32_kernel<256, 128, 4, 2, true, false", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_f32_wide bwd_d_a (C2)", "legs", "gemm_f32_wide_kernel<true, true, false>", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_f32_wide bwd_d_r (C2)", "legs", "gemm_f32_wide_kernel<true, false, false>", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_f32 256x128 bwd_d_a (C2; fallback since the wide kernel)", "legs", "gemm_f32_kernel<256, 128, 4, 2, true, true", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_f32 256x128 bwd_d_r (C2; fallback since the wide kernel)", "legs", "gemm_f32_kernel<256, 128, 4, 2, true, false", 16 * (C2_PAIR + 2 * HAT)),
     ("corr_normalise (one of two launches)", "legs", "corr_normalise_keep_kernel", 16 * 2 * HAT),
     ("corr_normalise_bwd", "legs", "corr_normalise_bwd_keep_kernel", 16 * 3 * HAT),
     ("warp_fwd align_set 256^2 x128 (C3)", "legs", "warp_fwd_kernel<false, true, 1, true>", NPIX_C3 * 40),
