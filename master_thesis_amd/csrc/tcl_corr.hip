@@ -1221,12 +1221,20 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
   const int ktiles = (g.K + BKH - 1) / BKH;
   const int total = ktiles * g.nseg;
 
-  // FULL: per-thread operand cursors, advanced by a block-uniform stride per k-tile (segment change: rewind + a_ss / b_ss)
-  const float *pa = FULL ? la.thread_base(Ab, g.a_ld, m0, tid) : nullptr;
-  const float *pb = FULL ? lb.thread_base(Bb, g.b_ld, n0, tid) : nullptr;
-  const int64_t a_st = la.step(g.a_ld), b_st = lb.step(g.b_ld), a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
+  // FULL: buffer-load cursors as in gemm_f32_kernel (descriptor + loop-invariant offsets + scalar k offset; the launcher
+  // checks the 31-bit bound)
+  const int64_t a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
+  uint32_t a_off[la.NV], b_off[lb.NV];
+  __amdgpu_buffer_rsrc_t ra, rb;
+  int sa = 0, sb = 0;
+  if (FULL) {
+    la.thread_offsets(a_off, g.a_ld, tid);
+    lb.thread_offsets(b_off, g.b_ld, tid);
+    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Ab + (A_KC ? (int64_t)m0 * g.a_ld : m0)), 0, 0x7fffffff, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Bb + (B_KC ? (int64_t)n0 * g.b_ld : n0)), 0, 0x7fffffff, 0x00020000);
+  }
   int kt_next = 1;
-  if (FULL) { la.load_full(pa, a_st); lb.load_full(pb, b_st); }
+  if (FULL) { la.load_buf(ra, a_off, 0); lb.load_buf(rb, b_off, 0); }
   else {
     la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
     lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
@@ -1237,11 +1245,11 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
     __syncthreads();
     if (t + 1 < total) {
       if (FULL) {
-        if (kt_next == ktiles) { kt_next = 0; pa += g.a_ss - (ktiles - 1) * a_k; pb += g.b_ss - (ktiles - 1) * b_k; }
-        else { pa += a_k; pb += b_k; }
+        if (kt_next == ktiles) { kt_next = 0; sa += (int)(g.a_ss - (ktiles - 1) * a_k) * 4; sb += (int)(g.b_ss - (ktiles - 1) * b_k) * 4; }
+        else { sa += (int)a_k * 4; sb += (int)b_k * 4; }
         ++kt_next;
-        la.load_full(pa, a_st);
-        lb.load_full(pb, b_st);
+        la.load_buf(ra, a_off, sa);
+        lb.load_buf(rb, b_off, sb);
       } else {
         const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
         la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BKH, g.M, g.K, tid);
@@ -1345,7 +1353,9 @@ static int launch_gemm_bf16(GemmArgs g, int nsplit, hipStream_t s, const char *w
   const bool vec = gemm_vec_ok(g, A_KC, B_KC);
   const dim3 grd((unsigned)blocks), blk(WM * WN * 64);
 #ifndef TCL_GEMM_NO_FULL
-  if (vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BKH == 0) {   // full tiles: cursor loads, no predication
+  if (vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BKH == 0 && (int64_t)BM * g.d_ld * 4 < (1LL << 31) &&
+      (int64_t)g.nseg * g.a_ss * 4 + (int64_t)(A_KC ? BM : g.K) * g.a_ld * 4 < (1LL << 31) &&
+      (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? BN : g.K) * g.b_ld * 4 < (1LL << 31)) {   // full tiles (31-bit buffer offsets): cursor loads, no predication
     if (nsplit == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 2, true>), grd, blk, 0, s, g);
     else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 1, true>), grd, blk, 0, s, g);
     return check_launch(what);
