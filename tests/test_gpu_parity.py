@@ -165,6 +165,7 @@ def _masks(rng, shape, p=0.9):
     (128, 256, 2, 16, 16, True),
     (32, 256, 1, 32, 32, False),
     (16, 512, 1, 32, 32, True),
+    (43, 256, 3, 16, 16, True),    # 129 tiles for d_r only (d_a: 43 tiles -> the 256 x 128 kernel), three segments, odd batch
 ])
 def test_corr4d_vs_oracle(mods, B, C, F, H, W, masked):
     rng = np.random.default_rng(B * 1000 + C)
