@@ -728,17 +728,19 @@ template <int ROWS, int PW, int NW, int BKT>
 struct DmaTile {
   static constexpr int PIECES = BKT * ROWS / 256, PER_WAVE = PIECES / NW, KPP = 256 / ROWS;   // k rows per piece
   static_assert(256 % ROWS == 0 && PIECES % NW == 0, "a k-tile must split into whole 1 KiB pieces per wave");
-  // this lane's source of piece j = 0 of k-tile 0; piece j lies j * jstep(ld) floats further, the next k-tile BKT * ld
-  __device__ __forceinline__ static const float *lane_base(const float *base, int64_t ld, int row0, int wid, int lane) {
+  // LDS-DMA through a buffer descriptor on the block's (row0, k-tile 0) element: this lane's byte offset of piece j = 0
+  // (loop-invariant register) + a scalar offset for the piece and the k-tile: `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`,
+  // no vector address arithmetic
+  __device__ __forceinline__ static uint32_t lane_offset(int64_t ld, int wid, int lane) {
     const int f = lane * 4, k = wid * KPP + f / ROWS, pos = f % ROWS;
     const int row = PW > 0 ? ((pos / 32) % PW) * (ROWS / PW) + (pos / (PW * 32)) * 32 + (pos & 31) : pos;
-    return base + (int64_t)k * ld + row0 + row;
+    return (uint32_t)k * (uint32_t)ld * 4u + (uint32_t)row * 4u;
   }
-  __device__ __forceinline__ static int64_t jstep(int64_t ld) { return (int64_t)NW * KPP * ld; }
-  __device__ __forceinline__ static void issue(const float *src, int64_t js, float *stage, int wid) {
+  __device__ __forceinline__ static int jstep_bytes(int64_t ld) { return (int)((int64_t)NW * KPP * ld * 4); }
+  __device__ __forceinline__ static void issue(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, int soff, int js, float *stage, int wid) {
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j)
-      __builtin_amdgcn_global_load_lds((glb_cvptr)(src + j * js), (lds_vptr)(stage + (j * NW + wid) * 256), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(stage + (j * NW + wid) * 256), 16, (int)voff, soff + j * js, 0, 0);
   }
 };
 
@@ -773,18 +775,20 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_glds_kernel(GemmArgs g) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const float *pa = DA::lane_base(g.A + (int64_t)(z / g.a_bdiv) * g.a_bs, g.a_ld, m0, wid, lane);
-  const float *pb = DB::lane_base(g.B + (int64_t)z * g.b_bs, g.b_ld, n0, wid, lane);
-  const int64_t a_js = DA::jstep(g.a_ld), b_js = DB::jstep(g.b_ld), a_k = (int64_t)BKT * g.a_ld, b_k = (int64_t)BKT * g.b_ld;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A + (int64_t)(z / g.a_bdiv) * g.a_bs + m0), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.B + (int64_t)z * g.b_bs + n0), 0, 0x7fffffff, 0x00020000);
+  const uint32_t a_vo = DA::lane_offset(g.a_ld, wid, lane), b_vo = DB::lane_offset(g.b_ld, wid, lane);
+  const int a_js = DA::jstep_bytes(g.a_ld), b_js = DB::jstep_bytes(g.b_ld), a_k = (int)((int64_t)BKT * g.a_ld * 4), b_k = (int)((int64_t)BKT * g.b_ld * 4);
+  int sa = 0, sb = 0;
   const int total = g.K / BKT;
 
   // prologue: tiles 0 .. NST-2 in flight
 #pragma unroll
   for (int st = 0; st < NST - 1; ++st)
     if (st < total) {
-      DA::issue(pa, a_js, smem + st * STAGE, wid);
-      DB::issue(pb, b_js, smem + st * STAGE + BKT * BM, wid);
-      pa += a_k; pb += b_k;
+      DA::issue(ra, a_vo, sa, a_js, smem + st * STAGE, wid);
+      DB::issue(rb, b_vo, sb, b_js, smem + st * STAGE + BKT * BM, wid);
+      sa += a_k; sb += b_k;
     }
   int rd = 0, wr = NST - 1;
   for (int t = 0; t < total; ++t) {
@@ -794,9 +798,9 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_glds_kernel(GemmArgs g) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (t + NST - 1 < total) {
-      DA::issue(pa, a_js, smem + wr * STAGE, wid);
-      DB::issue(pb, b_js, smem + wr * STAGE + BKT * BM, wid);
-      pa += a_k; pb += b_k;
+      DA::issue(ra, a_vo, sa, a_js, smem + wr * STAGE, wid);
+      DB::issue(rb, b_vo, sb, b_js, smem + wr * STAGE + BKT * BM, wid);
+      sa += a_k; sb += b_k;
     }
     mma_ktile_kmajor<BM, BN, WM, WN, BKT>(smem + rd * STAGE, smem + rd * STAGE + BKT * BM, acc, wid, lr, lh);
     rd = rd + 1 == NST ? 0 : rd + 1;
