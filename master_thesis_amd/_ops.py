@@ -157,33 +157,71 @@ class Corr1x1Fn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------- A3/A4 warp
+def _frame_runs(frames, f_total):
+    """[source frame of output frame 0, 1, ...] -> [(source start, output start, count)] of consecutive runs."""
+    runs, o = [], 0
+    while o < len(frames):
+        n = 1
+        while o + n < len(frames) and frames[o + n] == frames[o] + n:
+            n += 1
+        if frames[o] < 0 or frames[o] + n > f_total:
+            raise IndexError("frame index %d outside [0, %d)" % (frames[o], f_total))
+        runs.append((int(frames[o]), o, n))
+        o += n
+    return runs
+
+
+_MAX_FRAME_RUNS = 4   # more runs than this: gather the frames once (one copy) instead of one launch per run
+
+
 class WarpFn(torch.autograd.Function):
-    """x (B,C,F,H,W) [any strides with dense planes], v (B,1,F,H,W) | None, and either grid (B*F,H,W,2) or
-    theta (B*F,2,3) -> x_out as a (B,C,F,H,W) view of a (B,F,C,H,W) buffer (what the reference returns),
-    v_out likewise.  Gradients flow to x and to the grid / theta; v is data."""
+    """x (B,C,F,H,W) [any strides with dense planes], v (B,1,F,H,W) | None, and either grid (B*F',H,W,2) or
+    theta (B*F',2,3) -> x_out as a (B,C,F',H,W) view of a (B,F',C,H,W) buffer (what the reference returns),
+    v_out likewise.  Gradients flow to x and to the grid / theta; v is data.
+
+    `frames` (a list of F' source frame indices, default: all F in order) selects which frame of x / v each output frame
+    samples: `WarpFn(x, ..., frames=r_list)` == `WarpFn(x[:, :, r_list], ...)` without the gathered copy of the frames (the
+    `x[:, :, r_list]` of models/cpn.py:283-290 is an index kernel as long as the warp itself): every run of consecutive
+    indices is one launch on a strided view of x that writes its frames of the shared output (the C ABI takes strides)."""
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, v, grid, theta, align_corners, v_mode):
+    def forward(ctx, x, v, grid, theta, align_corners, v_mode, frames=None):
         dev = _require_device(x, v, grid, theta)
-        b, c, f, h, w = x.shape
+        b, c, f_src, h, w = x.shape
+        runs = [(0, 0, f_src)] if frames is None else _frame_runs([int(i) for i in frames], f_src)
+        ctx.gathered = None
+        if len(runs) > _MAX_FRAME_RUNS:
+            ctx.gathered = (torch.as_tensor([int(i) for i in frames], device=dev), f_src)   # backward scatters g_x back
+            x, v = x[:, :, list(frames)], (None if v is None else v[:, :, list(frames)])
+            f_src, runs = x.shape[2], [(0, 0, x.shape[2])]
+        f = sum(n for _, _, n in runs)
         xs = _planes(x, h, w)
         vs = None if v is None else _planes(v, h, w)
         gridc = None if grid is None else grid.contiguous()
         thetac = None if theta is None else theta.contiguous()
         x_out = torch.empty((b, f, c, h, w), dtype=torch.float32, device=dev)
         v_out = torch.empty((b, f, 1, h, w), dtype=torch.float32, device=dev) if vs is not None else None
+        whole = len(runs) == 1 and runs[0][2] == f
         with torch.cuda.device(dev):
-            _lib.call("tcl_warp_fwd",
-                      _p(xs), xs.stride(0), xs.stride(2), xs.stride(1),
-                      _p(vs), vs.stride(0) if vs is not None else 0, vs.stride(2) if vs is not None else 0,
-                      _p(gridc), _p(thetac),
-                      _p(x_out), x_out.stride(0), x_out.stride(1), x_out.stride(2),
-                      _p(v_out), v_out.stride(0) if v_out is not None else 0, v_out.stride(1) if v_out is not None else 0,
-                      b, f, c, h, w, int(align_corners), v_mode if vs is not None else _lib.VMODE_NONE, _stream(dev))
+            for src, dst, n in runs:
+                # the run's positions: rows b * F' + dst .. + n of grid / theta (a small dense copy unless the run is everything)
+                g_run = None if gridc is None else (gridc if whole else gridc.view(b, f, h, w, 2)[:, dst:dst + n].contiguous())
+                t_run = None if thetac is None else (thetac if whole else thetac.view(b, f, 2, 3)[:, dst:dst + n].contiguous())
+                xr, xo = xs[:, :, src:src + n], x_out[:, dst:dst + n]
+                vr = None if vs is None else vs[:, :, src:src + n]
+                vo = None if v_out is None else v_out[:, dst:dst + n]
+                _lib.call("tcl_warp_fwd",
+                          _p(xr), xs.stride(0), xs.stride(2), xs.stride(1),
+                          _p(vr), vs.stride(0) if vs is not None else 0, vs.stride(2) if vs is not None else 0,
+                          _p(g_run), _p(t_run),
+                          _p(xo), x_out.stride(0), x_out.stride(1), x_out.stride(2),
+                          _p(vo), v_out.stride(0) if v_out is not None else 0, v_out.stride(1) if v_out is not None else 0,
+                          b, n, c, h, w, int(align_corners), v_mode if vs is not None else _lib.VMODE_NONE, _stream(dev))
         ctx.save_for_backward(xs, gridc, thetac)
         ctx.align_corners = int(align_corners)
-        ctx.x_shape = tuple(x.shape)
+        ctx.x_shape = tuple(xs.shape)
+        ctx.runs, ctx.f_out = runs, f
         if v_out is not None:
             v_ret = v_out.transpose(1, 2)
             ctx.mark_non_differentiable(v_ret)
@@ -195,24 +233,40 @@ class WarpFn(torch.autograd.Function):
     @_bwd
     def backward(ctx, g_x_out, _g_v_out):
         xs, gridc, thetac = ctx.saved_tensors
-        b, c, f, h, w = ctx.x_shape
+        b, c, f_src, h, w = ctx.x_shape
+        runs, f = ctx.runs, ctx.f_out
         dev = xs.device
         go = _planes(g_x_out, h, w)
         need_x, need_grid, need_theta = ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        g_x = torch.zeros((b, c, f, h, w), dtype=torch.float32, device=dev) if need_x else None
+        g_x = torch.zeros((b, c, f_src, h, w), dtype=torch.float32, device=dev) if need_x else None
         g_grid = torch.empty_like(gridc) if (need_grid and gridc is not None) else None
         g_theta = torch.empty_like(thetac) if (need_theta and thetac is not None) else None
+        whole = len(runs) == 1 and runs[0][2] == f
         if need_x or g_grid is not None or g_theta is not None:
-            ws = _workspace(_lib.lib().tcl_warp_bwd_workspace_bytes(b, f, h, w, 1 if g_theta is not None else 0), dev)
             with torch.cuda.device(dev):
-                _lib.call("tcl_warp_bwd",
-                          _p(go), go.stride(0), go.stride(2), go.stride(1),
-                          _p(xs), xs.stride(0), xs.stride(2), xs.stride(1),
-                          _p(gridc), _p(thetac),
-                          _p(g_x), g_x.stride(0) if need_x else 0, g_x.stride(2) if need_x else 0, g_x.stride(1) if need_x else 0,
-                          _p(g_grid), _p(g_theta),
-                          b, f, c, h, w, ctx.align_corners, _p(ws), ws.numel(), _stream(dev))
-        return g_x, None, g_grid, g_theta, None, None
+                for src, dst, n in runs:
+                    g_run = None if gridc is None else (gridc if whole else gridc.view(b, f, h, w, 2)[:, dst:dst + n].contiguous())
+                    t_run = None if thetac is None else (thetac if whole else thetac.view(b, f, 2, 3)[:, dst:dst + n].contiguous())
+                    gg_run = None if g_grid is None else (g_grid if whole else torch.empty_like(g_run))
+                    gt_run = None if g_theta is None else (g_theta if whole else torch.empty_like(t_run))
+                    ws = _workspace(_lib.lib().tcl_warp_bwd_workspace_bytes(b, n, h, w, 1 if g_theta is not None else 0), dev)
+                    _lib.call("tcl_warp_bwd",
+                              _p(go[:, :, dst:dst + n]), go.stride(0), go.stride(2), go.stride(1),
+                              _p(xs[:, :, src:src + n]), xs.stride(0), xs.stride(2), xs.stride(1),
+                              _p(g_run), _p(t_run),
+                              _p(g_x[:, :, src:src + n]) if need_x else None, g_x.stride(0) if need_x else 0, g_x.stride(2) if need_x else 0,
+                              g_x.stride(1) if need_x else 0,
+                              _p(gg_run), _p(gt_run),
+                              b, n, c, h, w, ctx.align_corners, _p(ws), ws.numel(), _stream(dev))
+                    if not whole:
+                        if g_grid is not None:
+                            g_grid.view(b, f, h, w, 2)[:, dst:dst + n] = gg_run
+                        if g_theta is not None:
+                            g_theta.view(b, f, 2, 3)[:, dst:dst + n] = gt_run
+        if g_x is not None and ctx.gathered is not None:
+            idx, f_all = ctx.gathered
+            g_x = torch.zeros((b, c, f_all, h, w), dtype=torch.float32, device=dev).index_add_(2, idx, g_x)
+        return g_x, None, g_grid, g_theta, None, None, None
 
 
 class AffineGridFn(torch.autograd.Function):

@@ -57,12 +57,13 @@ def affine_align(x, m, y, theta_rt, r_list, training=False):
     """The affine_grid + grid_sample block of CPNet.align (models/cpn.py:280-295) / CPNOriginal.align
     (models/cpn_original.py:276-284): theta_rt (B*R,2,3) -> x_aligned (B,C,R,H,W), v_aligned (B,1,R,H,W) in {0,1},
     y_aligned | None.  The sampling grid is derived from theta inside the kernel and never stored."""
-    x_refs = x[:, :, r_list]
-    v_refs = 1 - m[:, :, r_list]
-    x_aligned, v_aligned = _ops.WarpFn.apply(x_refs, v_refs, None, theta_rt, False, _lib.VMODE_BILINEAR_THRESHOLD)
+    # the reference gathers x[:, :, r_list] / m[:, :, r_list] first (an index copy as long as the warp itself); here the warp
+    # reads the reference frames in place (WarpFn's `frames`)
+    frames = [int(i) for i in r_list]
+    x_aligned, v_aligned = _ops.WarpFn.apply(x, 1 - m, None, theta_rt, False, _lib.VMODE_BILINEAR_THRESHOLD, frames)
     y_aligned = None
     if not training and y is not None:
-        y_aligned, _ = _ops.WarpFn.apply(y[:, :, r_list], None, None, theta_rt, False, _lib.VMODE_NONE)
+        y_aligned, _ = _ops.WarpFn.apply(y, None, None, theta_rt, False, _lib.VMODE_NONE, frames)
     return x_aligned, v_aligned, y_aligned
 
 

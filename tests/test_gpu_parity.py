@@ -651,3 +651,38 @@ def test_context_matching_properties_full_size(mods):
     assert bool(none.any())
     assert torch.equal(m1[:, 0][none], torch.ones_like(m1[:, 0][none]))
     assert float(p1[:, C:2 * C].permute(0, 2, 3, 1)[none].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("frames", [[0, 1, 3, 4], [2], [4, 0, 1], [0, 2, 4, 1, 3], [1, 2, 3]])
+@pytest.mark.parametrize("use_theta", [True, False])
+def test_warp_frames_equals_gathered_frames(mods, frames, use_theta):
+    """WarpFn(x, ..., frames=r_list) (reference frames read in place, one launch per run of consecutive indices; more than
+    four runs fall back to one gather) == WarpFn(x[:, :, r_list], ...) bit for bit: outputs, visibility, and the gradients
+    to x (scatter-add into the full tensor), to theta and to the grid."""
+    from master_thesis_amd import _lib, _ops
+    rng = np.random.default_rng(len(frames) * 7 + use_theta)
+    B, C, F, H, W = 3, 3, 5, 40, 72
+    x = rng.random((B, C, F, H, W)).astype(np.float32)
+    v = _masks(rng, (B, 1, F, H, W), 0.8)
+    n = len(frames)
+    theta = (np.tile(np.eye(2, 3, dtype=np.float32), (B * n, 1, 1)) + 0.1 * rng.standard_normal((B * n, 2, 3))).astype(np.float32)
+    ident = np.stack(np.meshgrid(np.linspace(-1, 1, W), np.linspace(-1, 1, H)), axis=-1).astype(np.float32)
+    grid = (ident[None] * 0.95 + 0.05 * rng.standard_normal((B * n, 1, 1, 2))).astype(np.float32)
+    cot = rng.standard_normal((B, C, n, H, W)).astype(np.float32)
+
+    def run(gather):
+        tx = T(x, True)
+        pos = T(theta if use_theta else grid, True)
+        args = (None, pos) if use_theta else (pos, None)
+        if gather:
+            xo, vo = _ops.WarpFn.apply(tx[:, :, frames], T(v)[:, :, frames], args[0], args[1], False, _lib.VMODE_BILINEAR_THRESHOLD)
+        else:
+            xo, vo = _ops.WarpFn.apply(tx, T(v), args[0], args[1], False, _lib.VMODE_BILINEAR_THRESHOLD, frames)
+        gx, gp = torch.autograd.grad((xo * T(cot)).sum(), [tx, pos])
+        return N(xo), N(vo), N(gx), N(gp)
+
+    a, b = run(True), run(False)
+    assert_exact(b[0], a[0], what="x_out")
+    assert_exact(b[1], a[1], what="v_out")
+    assert_close(b[2], a[2], rtol=1e-6, atol=1e-6, what="g_x")        # float atomics: summation order
+    assert_close(b[3], a[3], rtol=1e-5, atol=1e-6, what="g_theta / g_grid")
