@@ -883,11 +883,22 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
     sb += more ? (wrap ? b_seg : b_k) : 0;
   };
 
+  constexpr bool BQ = !B_KC && !PERSIST;   // interleaved-column B fragments (needs the epilogue below)
   f32x4 af[2][TM], bf[2][TN];
   auto read_group = [&](auto setc, const float *st, int kg) {
     constexpr int set = decltype(setc)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[set][i] = read_frag<BM, A_KC>(st, wm0 + i * 32 + lr, kg * 8 + lh * 4);
+    if (BQ) {
+      // k-major B, interleaved columns: MFMA block j of this wave owns the columns wn0 + 4 * l + j (l = its 32 MFMA rows), so
+      // ONE ds_read_b128 at k brings that k's value for all four blocks (instead of four scalar reads per block)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(st + A_LDS + (kg * 8 + lh * 4 + e) * BN + wn0 + lr * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[set][j][e] = v[j];
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < TN; ++j) bf[set][j] = read_frag<BN, B_KC>(st + A_LDS, wn0 + j * 32 + lr, kg * 8 + lh * 4);
   };
@@ -904,7 +915,7 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   // instruction order of one group = 64 MFMAs + NR fragment reads (+ 8 LDS writes + 8 global loads in groups 0 and 1)
-  constexpr int NR = (A_KC ? 4 : 8) + (B_KC ? 4 : 8);   // per operand: 4 ds_read_b128, or 8 ds_read2_b32
+  constexpr int NR = (A_KC ? 4 : 8) + (B_KC || BQ ? 4 : 8);   // per operand: 4 ds_read_b128, or 8 ds_read2_b32
   auto deal_staged = [&]() {   // LDS reads cannot move across the LDS writes (may alias, as far as hipcc knows): reads first
 #pragma unroll
     for (int i = 0; i < NR; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
@@ -983,8 +994,44 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
   }
   if (!PERSIST) {
     const unsigned z = first / per_batch, local = first - z * per_batch;
+    const int m0 = (int)(local % g.tiles_m) * BM, n0 = (int)(local / g.tiles_m) * BN;
     __syncthreads();
-    gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, 2 * STAGE>(acc, smem, g, z, (int)(local % g.tiles_m) * BM, (int)(local / g.tiles_m) * BN, local / g.tiles_m);
+    if (BQ) {
+      // Interleaved columns: register r of the four blocks (i, 0..3) = four CONSECUTIVE columns wn0 + 4 * n_l + j of row
+      // wm0 + 32 i + lr (n_l = (r & 3) + 8 (r >> 2) + 4 lh, the MFMA's C/D row).  One pass per i: the (i, *) blocks of all four
+      // waves = 64 rows x 256 columns go through LDS (rows padded by 4 floats) and leave as whole 1 KB rows: buffer stores,
+      // four loop-invariant offsets per thread, the pass as a scalar offset.
+      constexpr int ELD = BN + 4;
+      static_assert(WM * 32 * ELD <= 2 * STAGE, "epilogue staging must fit the operand stages");
+      const int wm = wid / WN, wn = wid % WN;
+      float *Db = g.D + (int64_t)z * g.d_bs;
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(Db + (int64_t)m0 * g.d_ld + n0, 0, 0x7fffffff, 0x00020000);
+      const int d_ld4 = g.d_ld * 4;
+      constexpr int RPT = WM * 32 * (BN / 4) / NT;   // float4 per thread and pass (16)
+      const int rrow = tid / (BN / 4), rcol = (tid % (BN / 4)) * 4;   // readback: row, column of float4 k = 0; k-th: row + k * (NT / (BN / 4))
+      const int st_off = ((rrow >> 5) * (BM / WM) + (rrow & 31)) * d_ld4 + rcol * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (i > 0) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const f32x4 val = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+          const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          *reinterpret_cast<f32x4 *>(smem + (wm * 32 + lr) * ELD + wn * (BN / WN) + nl * 4) = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          // rows rrow + 4 k: k = 8 crosses from the first wave row's 32 rows (wm = 0) to the second's
+          const int row = rrow + k * (NT / (BN / 4));
+          const f32x4 val = *reinterpret_cast<const f32x4 *>(smem + row * ELD + rcol);
+          const int koff = ((row >> 5) * (BM / WM) + (row & 31)) * d_ld4 + rcol * 4 - st_off;   // compile-time multiple of d_ld4 per k
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, st_off, koff + i * 32 * d_ld4, 2 /* nt */);
+        }
+      }
+      return;
+    }
+    gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, 2 * STAGE>(acc, smem, g, z, m0, n0, local / g.tiles_m);
   }
 }
 
