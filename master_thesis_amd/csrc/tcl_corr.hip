@@ -624,10 +624,6 @@ __global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? 4 : 1
 
   f32x16 acc[TM][TN];   // defined by the first k-tile (see mma_ktile_kmajor<FIRST>)
 
-#ifdef TCL_GEMM_STAGGER
-  if (FULL && EPI == EPI_STORE && blockIdx.x < 1024)
-    for (int i = 0; i < (int)(blockIdx.x >> 8) * TCL_GEMM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
   TileLoader<BM, NT, A_KC, VEC> la;
   TileLoader<BN, NT, B_KC, VEC> lb;
   const int ktiles = (g.K + BK - 1) / BK;
