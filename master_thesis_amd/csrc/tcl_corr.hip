@@ -16,6 +16,7 @@
 // same permutation on both operands, so a k-contiguous operand is fetched from LDS with one ds_read_b128
 // per lane (rows padded to 36 floats: conflict-free) and an m-contiguous one with plain ds_read_b32.
 #include "tcl_common.h"
+#include <mutex>
 #include <type_traits>
 
 namespace tcl {
@@ -1031,22 +1032,34 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
   }
 }
 
+// Once per device and instantiation: raise the kernel's dynamic-LDS limit to what it needs (139-147 KB of the CU's 160 KB) and
+// read the CU count.  Returns the CU count, or 0 if the device refuses (the caller then takes the 64 x 64-wave-tile kernels).
 template <bool A_KC, bool B_KC, bool PERSIST>
-static int launch_gemm_wide(GemmArgs g, hipStream_t s, const char *what) {
+static int wide_kernel_ready() {
+  constexpr size_t lds = (2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) + (PERSIST ? 64 * 68 : 0)) * sizeof(float);
+  static std::mutex mu;
+  static int cus[64];   // 0 = not asked yet, -1 = refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cus[dev] == 0) {
+    int n = 0;
+    const bool ok = hipFuncSetAttribute((const void *)gemm_f32_wide_kernel<A_KC, B_KC, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0;
+    if (!ok) (void)hipGetLastError();   // a refusal is not an error of the call that asked
+    cus[dev] = ok ? n : -1;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+
+template <bool A_KC, bool B_KC, bool PERSIST>
+static int launch_gemm_wide(GemmArgs g, int cus, hipStream_t s, const char *what) {
   g.tiles_m = g.M / 256;
   g.tiles_n = g.N / 256;
   g.d_vec = aligned(g.D, 16) && g.d_ld % 4 == 0 && g.d_bs % 4 == 0;
   int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
-  if (PERSIST) {
-    int dev = 0, cus = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    TCL_REQUIRE(e == hipSuccess && cus > 0, TCL_ERR_LAUNCH, "%s: cannot read the CU count: %s", what, hipGetErrorString(e));
-    if (blocks > cus) blocks = cus;
-  }
+  if (PERSIST && blocks > cus) blocks = cus;
   constexpr size_t lds = (2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) + (PERSIST ? 64 * 68 : 0)) * sizeof(float);
-  const hipError_t e = hipFuncSetAttribute((const void *)gemm_f32_wide_kernel<A_KC, B_KC, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  TCL_REQUIRE(e == hipSuccess, TCL_ERR_LAUNCH, "%s: %zu bytes of LDS per block refused: %s", what, lds, hipGetErrorString(e));
   hipLaunchKernelGGL((gemm_f32_wide_kernel<A_KC, B_KC, PERSIST>), dim3((unsigned)blocks), dim3(256), lds, s, g);
   return check_launch(what);
 }
@@ -1651,7 +1664,8 @@ extern "C" int tcl_corr4d_contract(const void *fwd_workspace, float *out, int64_
 #define TCL_FWD_TILE 128, 128, 2, 2
 #endif
 #ifdef TCL_GEMM_WIDE_FWD
-  if (gemm_wide_ok(g)) return launch_gemm_wide<false, false, true>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
+  if (gemm_wide_ok(g))
+    if (const int cus = wide_kernel_ready<false, false, true>()) return launch_gemm_wide<false, false, true>(g, cus, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
 #endif
   return launch_gemm<TCL_FWD_TILE, false, false>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
 }
@@ -1727,7 +1741,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_ss = C * P; g.b_ss = P * P; g.a_bdiv = 1; g.nbatch = (int)B;
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, true>(g, nsplit, s, "tcl_corr4d_bwd(d_a bf16 gemm)");
 #ifndef TCL_GEMM_NO_WIDE
-    else if (gemm_wide_ok(g)) rc = launch_gemm_wide<true, true, false>(g, s, "tcl_corr4d_bwd(d_a gemm)");
+    else if (gemm_wide_ok(g) && wide_kernel_ready<true, true, false>()) rc = launch_gemm_wide<true, true, false>(g, 0, s, "tcl_corr4d_bwd(d_a gemm)");
 #endif
     else rc = launch_gemm<256, 128, 4, 2, true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
     if (rc) return rc;
@@ -1745,7 +1759,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, false>(g, nsplit, s, "tcl_corr4d_bwd(d_r bf16 gemm)");
 #ifndef TCL_GEMM_NO_WIDE
-    else if (gemm_wide_ok(g)) rc = launch_gemm_wide<true, false, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
+    else if (gemm_wide_ok(g) && wide_kernel_ready<true, false, false>()) rc = launch_gemm_wide<true, false, false>(g, 0, s, "tcl_corr4d_bwd(d_r gemm)");
 #endif
     else rc = launch_gemm<256, 128, 4, 2, true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
     if (rc) return rc;
