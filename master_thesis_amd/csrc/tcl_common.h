@@ -79,6 +79,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Exact n / d for n < 2^31 by a host-made multiplier (2 integer instructions; a run-time divisor otherwise costs hipcc's
+// ~20-instruction float-reciprocal sequence per division, per lane, even for block-uniform operands: no scalar division).
+struct FastDiv {
+  uint32_t m, sh, one;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return one ? n : (__umulhi(n, m) >> sh); }
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  if (d <= 1) return FastDiv{0, 0, 1};
+  const int s = 32 - __builtin_clz(d - 1);   // ceil(log2 d)
+  return FastDiv{(uint32_t)((((uint64_t)1 << (31 + s)) + d - 1) / d), (uint32_t)(s - 1), 0};
+}
+
 // Bijective XCD-aware remap of a 1-D block id: blocks are dealt round-robin over the 8 XCDs, so give each
 // XCD a contiguous chunk of the logical tile order (neighbouring tiles then share one L2).
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {

@@ -22,6 +22,7 @@ struct WarpArgs {
   int align_corners, v_mode;
   float stepx, stepy;  // 2/(W-1), 2/(H-1) (torch.linspace step), divided on the host
   int gf;              // frames per XCD unit (see warp_block): NF when the frames of a batch item share one source frame
+  FastDiv fd_w, fd_nf; // / W (pixel -> row), / NF (image -> batch item)
 };
 
 // Grid (8, chunks per unit, units / 8) -> (image n, 256-pixel chunk).  Workgroups are dealt round-robin over the 8 XCDs in
@@ -182,10 +183,10 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
 template <bool HAS_THETA, bool W2, int VMODE, bool C3>
 __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chunk) {
   const int H = a.H, W = a.W;
-  const int b = n / a.NF, f = n - b * a.NF;
+  const int b = (int)a.fd_nf.div((unsigned)n), f = n - b * a.NF;
   const int pix = chunk * 256 + threadIdx.x;   // flattened: every wave reads / writes 256 contiguous, aligned bytes per plane
   if (pix >= H * W) return;
-  const int y = pix / W, x = pix - y * W;
+  const int y = (int)a.fd_w.div((unsigned)pix), x = pix - y * W;
   const bool ac = a.align_corners != 0;
   float gx, gy;
   if (HAS_THETA) {
@@ -261,6 +262,7 @@ struct WarpBwdArgs {
   int NB, NF, C, H, W;
   int align_corners;
   float stepx, stepy;
+  FastDiv fd_w, fd_nf; // / W (pixel -> row), / NF (image -> batch item)
 };
 
 // 2-D grid (chunk of 256 consecutive pixels of the flattened image, image), block 256; same straight-line structure as
@@ -275,11 +277,11 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
 #else
   const int n = blockIdx.y, chunk = blockIdx.x;
 #endif
-  const int b = n / a.NF, f = n - b * a.NF;
+  const int b = (int)a.fd_nf.div((unsigned)n), f = n - b * a.NF;
   const int pix0 = chunk * 256 + threadIdx.x;
   const bool ok = pix0 < HW;
   const int pix = ok ? pix0 : HW - 1;          // lanes past the image repeat its last pixel; nothing of theirs is stored
-  const int y = pix / W, x = pix - y * W;
+  const int y = (int)a.fd_w.div((unsigned)pix), x = pix - y * W;
   const bool ac = a.align_corners != 0;
   const float mx = ac ? 0.5f * (float)(W - 1) : 0.5f * (float)W;
   const float my = ac ? 0.5f * (float)(H - 1) : 0.5f * (float)H;
@@ -472,7 +474,7 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
   const int trow = tile / tiles_x;
   const int lx = threadIdx.x & 63, ly = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ty0 = trow * TILE_H + ly * TILE_K, tx0 = (tile - trow * tiles_x) * TILE_W;   // this wave's strip: rows ty0 .. ty0 + TILE_K - 1
-  const int b = n / a.NF, f = n - b * a.NF;
+  const int b = (int)a.fd_nf.div((unsigned)n), f = n - b * a.NF;
   const bool ac = a.align_corners != 0;
   const float mx = ac ? 0.5f * (float)(W - 1) : 0.5f * (float)W;
   const float my = ac ? 0.5f * (float)(H - 1) : 0.5f * (float)H;
@@ -644,7 +646,8 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
   TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536 && cdiv(H * W, 256) * gf < 65536, TCL_ERR_SHAPE,
               "tcl_warp_fwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   WarpArgs a{x, x_sb, x_sf, x_sc, v, v_sb, v_sf, grid, theta, x_out, xo_sb, xo_sf, xo_sc, v_out, vo_sb, vo_sf,
-             (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H), (int)gf};
+             (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H), (int)gf,
+             make_fastdiv((uint32_t)W), make_fastdiv((uint32_t)NF)};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grd = warp_grid(cdiv(cdiv(H * W, 256), theta ? FwdIters<true>::value : FwdIters<false>::value), a.gf, NB * NF), blk(256);
   const bool c3 = x_out != nullptr && C == 3;
@@ -709,7 +712,8 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
     partial = (float *)workspace;
   }
   WarpBwdArgs a{grad_x_out, go_sb, go_sf, go_sc, x, x_sb, x_sf, x_sc, grid, theta, g_x, gx_sb, gx_sf, gx_sc,
-                g_grid, partial, (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, lin_step(W), lin_step(H)};
+                g_grid, partial, (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, lin_step(W), lin_step(H),
+                make_fastdiv((uint32_t)W), make_fastdiv((uint32_t)NF)};
   hipStream_t s = (hipStream_t)stream;
 #ifdef TCL_WARP_BWD_XCD
   const dim3 grd = warp_grid(per, 1, N), blk(256);
