@@ -597,7 +597,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
 // writes that pair to g.D as float2 at [z][m][n-tile] (the volume itself never reaches HBM).
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int EPI, bool FULL = false>
-__global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? 4 : 1)) gemm_f32_kernel(GemmArgs g) {   // full-tile store kernels: 4 waves per SIMD (<= 128 registers)
+__global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? ((BM / WM) * (BN / WN) > 64 * 64 ? 2 : 4) : 1)) gemm_f32_kernel(GemmArgs g) {   // full-tile store kernels: 4 waves per SIMD (<= 128 registers)
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_LDS = A_KC ? BM * KC_LD : BK * BM;
