@@ -837,13 +837,7 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
   const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
   const int lr = lane & 31, lh = lane >> 5;
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc[TM][TN];   // defined by the first k-tile of every output tile (mma_group<FIRST>: C = inline zero)
 
   TileLoader<BM, NT, A_KC, true> la;
   TileLoader<BN, NT, B_KC, true> lb;
@@ -880,15 +874,24 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
     sb += more ? (wrap ? b_seg : b_k) : 0;
   };
 
-  constexpr bool BQ = !B_KC && !PERSIST;   // interleaved-column B fragments (needs the epilogue below)
+  // k-major operands are read INTERLEAVED: MFMA block i (j) of this wave owns the rows (columns) base + 4 * l + i, l = the
+  // MFMA's 32 row / column index, so ONE ds_read_b128 at a k brings that k's value for all four blocks (instead of four scalar
+  // reads per block); the epilogues below undo the interleave.  k-contiguous operands keep block i = rows base + 32 i + l.
+  constexpr bool AQ = !A_KC, BQ = !B_KC;
   f32x4 af[2][TM], bf[2][TN];
   auto read_group = [&](auto setc, const float *st, int kg) {
     constexpr int set = decltype(setc)::value;
+    if (AQ) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(st + (kg * 8 + lh * 4 + e) * BM + wm0 + lr * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[set][i][e] = v[i];
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[set][i] = read_frag<BM, A_KC>(st, wm0 + i * 32 + lr, kg * 8 + lh * 4);
     if (BQ) {
-      // k-major B, interleaved columns: MFMA block j of this wave owns the columns wn0 + 4 * l + j (l = its 32 MFMA rows), so
-      // ONE ds_read_b128 at k brings that k's value for all four blocks (instead of four scalar reads per block)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(st + A_LDS + (kg * 8 + lh * 4 + e) * BN + wn0 + lr * 4);
@@ -899,20 +902,23 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) bf[set][j] = read_frag<BN, B_KC>(st + A_LDS, wn0 + j * 32 + lr, kg * 8 + lh * 4);
   };
-  auto mma_group = [&](auto setc) {
+  auto mma_group = [&](auto setc, auto firstc) {
     constexpr int set = decltype(setc)::value;
+    constexpr bool FIRST = decltype(firstc)::value;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[set][j][e], af[set][i][e], acc[i][j], 0, 0, 0);   // transposed tile, see gemm_epilogue
+        for (int j = 0; j < TN; ++j) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[set][j][e], af[set][i][e], FIRST && e == 0 ? zero : acc[i][j], 0, 0, 0);   // transposed tile
+        }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   // instruction order of one group = 64 MFMAs + NR fragment reads (+ 8 LDS writes + 8 global loads in groups 0 and 1)
-  constexpr int NR = (A_KC ? 4 : 8) + (B_KC || BQ ? 4 : 8);   // per operand: 4 ds_read_b128, or 8 ds_read2_b32
+  constexpr int NR = 8;   // 4 ds_read_b128 per operand
   auto deal_staged = [&]() {   // LDS reads cannot move across the LDS writes (may alias, as far as hipcc knows): reads first
 #pragma unroll
     for (int i = 0; i < NR; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
@@ -940,7 +946,8 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
   read_group(S0{}, smem, 0);
   __builtin_amdgcn_sched_barrier(0);
   // one k-tile out of LDS stage PAR (compile-time: every LDS address of the loop is then a loop-invariant base + an immediate)
-  auto ktile = [&](auto par) {
+  using NO = std::false_type;
+  auto ktile = [&](auto par, auto firstc) {
     constexpr int PAR = decltype(par)::value;
     const float *cur = smem + PAR * STAGE;
     float *nxt = smem + (1 - PAR) * STAGE;
@@ -951,84 +958,85 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
     read_group(S1{}, cur, 1);
     la.template store<0>(nxt, tid);
     la.load_buf(ra, a_off, sa);
-    mma_group(S0{});
+    mma_group(S0{}, firstc);
     deal_staged();
     // group 1: the B image likewise
     read_group(S0{}, cur, 2);
     lb.template store<0>(nxt + A_LDS, tid);
     lb.load_buf(rb, b_off, sb);
-    mma_group(S1{});
+    mma_group(S1{}, NO{});
     deal_staged();
     advance();
     // group 2: the k-tile's last fragments
     read_group(S1{}, cur, 3);
-    mma_group(S0{});
+    mma_group(S0{}, NO{});
     deal_reads();
     __syncthreads();   // every wave: done reading `cur`, done writing `nxt`
     read_group(S0{}, nxt, 0);
-    mma_group(S1{});
+    mma_group(S1{}, NO{});
     deal_reads();
   };
-  // two loops, so that the accumulators' way out is not part of the hot loop's register allocation: the inner one runs over
-  // the k-tiles of one output tile (an even number: the launcher checks), two per trip; the staging pipeline (cursors, LDS
-  // stages) runs on across output tiles
-  for (int tile_done = 0; tile_done < count; ++tile_done) {
-    for (int kk = 0; kk < per_tile; kk += 2) {
-      ktile(S0{});
-      ktile(S1{});
+  // The accumulators' way out when an operand is interleaved: one pass per i (the (i, *) blocks of all four waves = 64 rows x 256
+  // columns) through a free LDS stage (exactly 64 KB: no room for padding, so the float4 columns are XOR-swizzled with the
+  // row: 2-way conflicts at worst), leaving as whole 1 KB rows: buffer stores, loop-invariant per-thread offsets, the pass as a
+  // scalar offset.  Register r of the four blocks (i, 0..3) = four consecutive columns wn0 + 4 n_l + j, n_l = (r & 3) +
+  // 8 (r >> 2) + 4 lh (BQ); with AQ block i's row l is row wm0 + 4 l + i of the tile, else wm0 + 32 i + l.
+  auto store_tile_interleaved = [&](float *stg, unsigned z, int m0, int n0) {
+    static_assert(WM * 32 * BN <= STAGE, "epilogue staging must fit one operand stage");
+    const int wm = wid / WN, wn = wid % WN;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(g.D + (int64_t)z * g.d_bs + (int64_t)m0 * g.d_ld + n0, 0, 0x7fffffff, 0x00020000);
+    const int d_ld4 = g.d_ld * 4;
+    constexpr int RPT = WM * 32 * (BN / 4) / NT;       // float4 per thread and pass (16): staged rows rrow + 4 k
+    const int rrow = tid / (BN / 4), rc4 = tid % (BN / 4);
+    const int row_bytes = (AQ ? 4 : 1) * d_ld4;       // distance of two consecutive staged rows of one wave row in D
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (i > 0) __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const f32x4 val = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        *reinterpret_cast<f32x4 *>(stg + (wm * 32 + lr) * BN + ((wn * (BN / WN) + nl * 4) ^ (lr << 2))) = val;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        // staged row rrow + 4 k: wave row (k >> 3), l = 4 (k & 7) + rrow
+        const int l = 4 * (k & 7) + rrow;
+        const f32x4 val = *reinterpret_cast<const f32x4 *>(stg + ((k >> 3) * 32 + l) * BN + ((rc4 * 4) ^ (l << 2)));
+        const int voff = rrow * row_bytes + rc4 * 16;
+        const int soff = (k >> 3) * (BM / WM) * d_ld4 + 4 * (k & 7) * row_bytes + (AQ ? i : i * 32) * d_ld4;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, voff, soff, 2 /* nt */);
+      }
     }
-    if (PERSIST) {   // output tile complete: store it, start the next one from zero
+  };
+  // two loops, so that the accumulators' way out is not part of the hot loop's register allocation: the inner one runs over
+  // the k-tiles of one output tile (an even number: the launcher checks), two per trip, the first from a zero C; the staging
+  // pipeline (cursors, LDS stages) runs on across output tiles
+  for (int tile_done = 0; tile_done < count; ++tile_done) {
+    ktile(S0{}, std::true_type{});
+    ktile(S1{}, NO{});
+    for (int kk = 2; kk < per_tile; kk += 2) {
+      ktile(S0{}, NO{});
+      ktile(S1{}, NO{});
+    }
+    if (PERSIST) {   // output tile complete: store it.  Stage 1 (the last k-tile's) is free: stage 0 already holds the next tile's first k-tile
       const unsigned lin = first + tile_done * stride, z = lin / per_batch, local = lin - z * per_batch;
-      gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, EPI_LDS>(acc, smem + 2 * STAGE, g, z, (int)(local % g.tiles_m) * BM, (int)(local / g.tiles_m) * BN,
-                                                              local / g.tiles_m);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      const int m0 = (int)(local % g.tiles_m) * BM, n0 = (int)(local / g.tiles_m) * BN;
+      if (AQ || BQ) {
+        store_tile_interleaved(smem + STAGE, z, m0, n0);
+        __syncthreads();   // read back by everyone before the next k-tile restages stage 1
+      } else {
+        gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, EPI_LDS>(acc, smem + 2 * STAGE, g, z, m0, n0, local / g.tiles_m);
+      }
     }
   }
   if (!PERSIST) {
     const unsigned z = first / per_batch, local = first - z * per_batch;
     const int m0 = (int)(local % g.tiles_m) * BM, n0 = (int)(local / g.tiles_m) * BN;
     __syncthreads();
-    if (BQ) {
-      // Interleaved columns: register r of the four blocks (i, 0..3) = four CONSECUTIVE columns wn0 + 4 * n_l + j of row
-      // wm0 + 32 i + lr (n_l = (r & 3) + 8 (r >> 2) + 4 lh, the MFMA's C/D row).  One pass per i: the (i, *) blocks of all four
-      // waves = 64 rows x 256 columns go through LDS (rows padded by 4 floats) and leave as whole 1 KB rows: buffer stores,
-      // four loop-invariant offsets per thread, the pass as a scalar offset.
-      constexpr int ELD = BN + 4;
-      static_assert(WM * 32 * ELD <= 2 * STAGE, "epilogue staging must fit the operand stages");
-      const int wm = wid / WN, wn = wid % WN;
-      float *Db = g.D + (int64_t)z * g.d_bs;
-      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(Db + (int64_t)m0 * g.d_ld + n0, 0, 0x7fffffff, 0x00020000);
-      const int d_ld4 = g.d_ld * 4;
-      constexpr int RPT = WM * 32 * (BN / 4) / NT;   // float4 per thread and pass (16)
-      const int rrow = tid / (BN / 4), rcol = (tid % (BN / 4)) * 4;   // readback: row, column of float4 k = 0; k-th: row + k * (NT / (BN / 4))
-      const int st_off = ((rrow >> 5) * (BM / WM) + (rrow & 31)) * d_ld4 + rcol * 4;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (i > 0) __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const f32x4 val = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-          const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          *reinterpret_cast<f32x4 *>(smem + (wm * 32 + lr) * ELD + wn * (BN / WN) + nl * 4) = val;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-          // rows rrow + 4 k: k = 8 crosses from the first wave row's 32 rows (wm = 0) to the second's
-          const int row = rrow + k * (NT / (BN / 4));
-          const f32x4 val = *reinterpret_cast<const f32x4 *>(smem + row * ELD + rcol);
-          const int koff = ((row >> 5) * (BM / WM) + (row & 31)) * d_ld4 + rcol * 4 - st_off;   // compile-time multiple of d_ld4 per k
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, st_off, koff + i * 32 * d_ld4, 2 /* nt */);
-        }
-      }
-      return;
-    }
-    gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, 2 * STAGE>(acc, smem, g, z, m0, n0, local / g.tiles_m);
+    if (AQ || BQ) store_tile_interleaved(smem, z, m0, n0);
+    else gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, 2 * STAGE>(acc, smem, g, z, m0, n0, local / g.tiles_m);
   }
 }
 
@@ -1036,7 +1044,7 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
 // read the CU count.  Returns the CU count, or 0 if the device refuses (the caller then takes the 64 x 64-wave-tile kernels).
 template <bool A_KC, bool B_KC, bool PERSIST>
 static int wide_kernel_ready() {
-  constexpr size_t lds = (2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) + (PERSIST ? 64 * 68 : 0)) * sizeof(float);
+  constexpr size_t lds = (2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) + (PERSIST && A_KC && B_KC ? 64 * 68 : 0)) * sizeof(float);
   static std::mutex mu;
   static int cus[64];   // 0 = not asked yet, -1 = refused
   int dev = 0;
@@ -1059,7 +1067,7 @@ static int launch_gemm_wide(GemmArgs g, int cus, hipStream_t s, const char *what
   g.d_vec = aligned(g.D, 16) && g.d_ld % 4 == 0 && g.d_bs % 4 == 0;
   int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
   if (PERSIST && blocks > cus) blocks = cus;
-  constexpr size_t lds = (2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) + (PERSIST ? 64 * 68 : 0)) * sizeof(float);
+  constexpr size_t lds = (2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) + (PERSIST && A_KC && B_KC ? 64 * 68 : 0)) * sizeof(float);
   hipLaunchKernelGGL((gemm_f32_wide_kernel<A_KC, B_KC, PERSIST>), dim3((unsigned)blocks), dim3(256), lds, s, g);
   return check_launch(what);
 }
