@@ -198,6 +198,42 @@ def test_corr4d_properties_full_size(mods):
     assert torch.equal(out[0][vis[0] == 0], torch.zeros_like(out[0][vis[0] == 0]))
 
 
+def test_corr4d_c2_full_batch_vs_torch_fp32(mods):
+    """BASELINE configs[1] at its full size (16 pairs, C = 256, 64 x 64): the shape bench.py times, i.e. the 128 x 128 forward
+    kernel on 16,384 tiles and the wide backward kernels on 256.  Too large for the numpy oracle in a test, so the reference
+    here is the same formula (utils/correlation.py:28-54) in stock fp32 torch ops on the GPU (rocBLAS bmm + autograd):
+    an independent implementation of a floating-point kernel, held to the fp32 bar."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B, C, F, S = 16, 256, 1, 64
+    xt = torch.randn(B, C, S, S, generator=g).to(DEV).requires_grad_(True)
+    xr = torch.randn(B, C, F, S, S, generator=g).to(DEV).requires_grad_(True)
+    vt = (torch.rand(B, 1, S, S, generator=g) < 0.9).float().to(DEV)
+    vr = (torch.rand(B, 1, F, S, S, generator=g) < 0.9).float().to(DEV)
+    cot = torch.randn(B, F, S * S, S * S, generator=g).to(DEV)
+
+    out = mods["corr"].compute_masked_4d_correlation(xt, vt, xr, vr)
+    gt, gr = torch.autograd.grad(out, [xt, xr], grad_outputs=cot.view_as(out))
+
+    xt2, xr2 = xt.detach().clone().requires_grad_(True), xr.detach().clone().requires_grad_(True)
+    a = (xt2 * vt).reshape(B, C, -1)
+    a = a / (a.norm(dim=1, keepdim=True) + 1e-9)
+    r = (xr2 * vr).reshape(B, C, F, -1)
+    r = r / (r.norm(dim=1, keepdim=True) + 1e-9)
+    ref = torch.einsum("bcp,bcfq->bfpq", a, r)
+    rgt, rgr = torch.autograd.grad(ref, [xt2, xr2], grad_outputs=cot)
+
+    def close(got, want, what):
+        got, want = got.detach(), want.detach()
+        err = (got - want).abs()
+        tol = 1e-5 * float(want.abs().max()) + 1e-4 * want.abs()
+        bad = int((err > tol).sum())
+        assert bad == 0, "%s: %d / %d off, worst %.3e" % (what, bad, err.numel(), float((err - tol).max()))
+
+    close(out.reshape(B, F, S * S, S * S), ref, "corr4d fwd")
+    close(gt, rgt, "corr4d g_x_t")
+    close(gr, rgr, "corr4d g_x_r")
+
+
 @pytest.mark.parametrize("B,C,F,S", [(2, 32, 2, 8), (1, 64, 1, 16), (1, 256, 1, 64), (2, 19, 3, 5)])
 def test_fused_argmax_flow(mods, B, C, F, S):
     """corr4d + corr_to_flow fused == corr_to_flow(corr4d(...)) exactly (same arithmetic), and == the oracle wherever the
