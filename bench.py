@@ -199,6 +199,11 @@ def _legs_corr(dev, corr, add, lib, stream, sp):
     ms = time_rotating([lambda: _lib.call("tcl_corr4d_bwd", _p(cot), _p(xt), _p(vt), _p(xr), _p(vr), _p(ws), _p(gt), _p(gr), B, C, F, P, 0,
                                           _p(ws2), ws2.numel(), sp)], stream, rounds=20, warm=40)
     add("corr_bwd", "2 x gemm_f32_wide_kernel (256x256 tiles) + corr_normalise_bwd (tcl_corr4d_bwd)", ms, flops=2 * flops)
+    # the two products alone (each still followed by its normalise-backward kernel, ~38 us of the figure)
+    for name, a_t, a_r in (("corr_bwd_d_a", gt, None), ("corr_bwd_d_r", None, gr)):
+        ms = time_rotating([lambda: _lib.call("tcl_corr4d_bwd", _p(cot), _p(xt), _p(vt), _p(xr), _p(vr), _p(ws), _p(a_t), _p(a_r), B, C, F, P, 0,
+                                              _p(ws2), ws2.numel(), sp)], stream, rounds=20, warm=20)
+        add(name, "gemm_f32_wide_kernel<%s> + corr_normalise_bwd" % ("k-contiguous G" if a_t is not None else "k-major G"), ms, flops=flops)
     del out, ws, ws2, gt, gr
 
 
