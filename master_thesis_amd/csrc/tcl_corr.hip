@@ -471,6 +471,73 @@ __device__ __forceinline__ void mma_ktile_kmajor(const float *As, const float *B
     }
 }
 
+// The same k-tile with INTERLEAVED fragments (TM = TN = 2, unpermuted [k][rows] images): MFMA block i of a wave owns the rows
+// wm0 + 2 l + i (l = the MFMA's 32 column index), block j the columns wn0 + 2 l + j, so one 8-byte read at a k serves both
+// blocks of an operand and ds_read2_b64 two consecutive k: 16 LDS reads per k-tile instead of 32.  Needs store_tile_il below.
+template <int BM, int BN, int WM, int WN, int BKT, bool FIRST = false>
+__device__ __forceinline__ void mma_ktile_kmajor_il(const float *As, const float *Bs, f32x16 (&acc)[2][2], int wid, int lr, int lh) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int NP = BKT / 4;   // pairs of slices per k-tile
+  const float *ap = As + (lh * 4) * BM + (wid / WN) * (BM / WM) + 2 * lr, *bp = Bs + (lh * 4) * BN + (wid % WN) * (BN / WN) + 2 * lr;
+  f32x2 a_cur[2], b_cur[2], a_nxt[2], b_nxt[2];   // [k of the pair][block]
+#pragma unroll
+  for (int s = 0; s < 2; ++s) { a_cur[s] = *reinterpret_cast<const f32x2 *>(ap + s * BM); b_cur[s] = *reinterpret_cast<const f32x2 *>(bp + s * BN); }
+  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if (p + 1 < NP) {
+      const int kk = ((p + 1) >> 1) * 8 + ((p + 1) & 1) * 2;   // first k row of the next pair (this lane half adds lh * 4)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { a_nxt[s] = *reinterpret_cast<const f32x2 *>(ap + (kk + s) * BM); b_nxt[s] = *reinterpret_cast<const f32x2 *>(bp + (kk + s) * BN); }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[s][j], a_cur[s][i], FIRST && p == 0 && s == 0 ? zero : acc[i][j], 0, 0, 0);
+        }
+    if (p + 1 < NP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS reads of pair p+1
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                   // MFMAs of pair p
+    if (p + 1 < NP) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { a_cur[s] = a_nxt[s]; b_cur[s] = b_nxt[s]; }
+    }
+  }
+}
+
+// Epilogue of the interleaved accumulators of a 128 x 128 tile (2 x 2 waves): one pass per i; the (i, *) blocks of the four
+// waves = 64 staged rows (wave row, l) x 128 columns fill the 32 KB operand buffer exactly, float4 columns XOR-swizzled with
+// the row; they leave as whole 512-byte rows (buffer stores, loop-invariant offsets, the pass as a scalar offset).
+// Registers r, r + 1 (r even) of blocks (i, 0), (i, 1) = the four consecutive columns wn0 + 2 n_l .. + 3, n_l = (r & 3) +
+// 8 (r >> 2) + 4 lh; staged row (wave row w, l) = row w * 64 + 2 l + i of the tile.
+__device__ __forceinline__ void store_tile_il(f32x16 (&acc)[2][2], float *stg, const GemmArgs &g, unsigned z, int m0, int n0) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5, wm = wid >> 1, wn = wid & 1;
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(g.D + (int64_t)z * g.d_bs + (int64_t)m0 * g.d_ld + n0, 0, 0x7fffffff, 0x00020000);
+  const int d_ld4 = g.d_ld * 4;
+  const int rrow = tid >> 5, rc4 = tid & 31;   // readback: staged rows rrow + 8 k, float4 column rc4
+  const int voff = rrow * 2 * d_ld4 + rc4 * 16;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i > 0) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x4 val = {acc[i][0][r], acc[i][1][r], acc[i][0][r + 1], acc[i][1][r + 1]};
+      const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      *reinterpret_cast<f32x4 *>(stg + (wm * 32 + lr) * 128 + ((wn * 64 + 2 * nl) ^ (lr << 2))) = val;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int l = 8 * (k & 3) + rrow;   // staged row rrow + 8 k = wave row (k >> 2), l
+      const f32x4 val = *reinterpret_cast<const f32x4 *>(stg + ((k >> 2) * 32 + l) * 128 + ((rc4 * 4) ^ (l << 2)));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, voff, ((k >> 2) * 64 + 16 * (k & 3) + i) * d_ld4, 2 /* nt */);
+    }
+  }
+}
+
 enum { EPI_STORE = 0, EPI_ARGMAX = 1 };
 
 // Epilogue of the fp32 GEMM kernels (the k-loop has ended on a barrier: `smem`, SMEM floats, is free again).
@@ -658,11 +725,16 @@ __global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? ((BM 
     lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
   }
   constexpr bool PIPE = !A_KC && !B_KC;   // hand-pipelined fragment reads, permuted LDS rows
+#ifdef TCL_GEMM_FWD_IL   // A/B switch: interleaved fragments (half the LDS reads) for the full 128 x 128 store tiles
+  constexpr bool IL = PIPE && FULL && EPI == EPI_STORE && BM == 128 && BN == 128 && WM == 2 && WN == 2;
+#else
+  constexpr bool IL = false;
+#endif
   auto ktile = [&](auto firstc, int t) {
     constexpr bool FIRST = decltype(firstc)::value;
     if (!(TCL_GEMM_ABL & 2) || t == 0) {
-      la.template store<PIPE ? WM : 0>(As, tid);
-      lb.template store<PIPE ? WN : 0>(Bs, tid);
+      la.template store<PIPE && !IL ? WM : 0>(As, tid);
+      lb.template store<PIPE && !IL ? WN : 0>(Bs, tid);
     }
     if (!(TCL_GEMM_ABL & 1)) __syncthreads();
     if (t + 1 < total && !(TCL_GEMM_ABL & 4)) {  // prefetch the next tile while this one is multiplied
@@ -684,7 +756,9 @@ __global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? ((BM 
         lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BK, g.N, g.K, tid);
       }
     }
-    if (PIPE) {
+    if constexpr (IL) {
+      mma_ktile_kmajor_il<BM, BN, WM, WN, BK, FIRST>(As, Bs, acc, wid, lr, lh);
+    } else if (PIPE) {
       mma_ktile_kmajor<BM, BN, WM, WN, BK, FIRST>(As, Bs, acc, wid, lr, lh);
     } else
 #pragma unroll
@@ -710,7 +784,8 @@ __global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? ((BM 
   ktile(std::true_type{}, 0);   // peeled: its MFMAs start from an inline zero
   for (int t = 1; t < total; ++t) ktile(std::false_type{}, t);
 
-  gemm_epilogue<BM, BN, WM, WN, EPI, FULL, A_LDS + B_LDS>(acc, smem, g, z, m0, n0, tn);
+  if constexpr (IL) store_tile_il(acc, smem, g, z, m0, n0);
+  else gemm_epilogue<BM, BN, WM, WN, EPI, FULL, A_LDS + B_LDS>(acc, smem, g, z, m0, n0, tn);
 }
 
 // ---- forward contraction, LDS-DMA staging.  Full tiles only, both operands k-major (M % BM == N % BN == K % BKT == 0, 16-byte
@@ -1103,7 +1178,7 @@ static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
   // full tiles; and the byte offsets of one block's operand panels (rows x ld, all segments) fit the 31 bits of its buffer loads
   const bool full = vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 &&
                     (int64_t)g.nseg * g.a_ss * 4 + (int64_t)(A_KC ? BM : g.K) * g.a_ld * 4 < (1LL << 31) &&
-                    (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? BN : g.K) * g.b_ld * 4 < (1LL << 31) && (int64_t)BM * g.d_ld * 4 < (1LL << 31);
+                    (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? BN : g.K) * g.b_ld * 4 < (1LL << 31) && (int64_t)BM * g.d_ld * 4 < (1LL << 31) && g.d_vec;
 #ifdef TCL_GEMM_GLDS   // A/B switch: LDS-DMA staging for the forward contraction (measured: no gain)
   if constexpr (!A_KC && !B_KC) if (full && g.nseg == 1 && g.K % TCL_GLDS_BK == 0) {
     hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, WM, WN, TCL_GLDS_BK, TCL_GLDS_NST, EPI>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
