@@ -428,6 +428,9 @@ __device__ __forceinline__ f32x4 read_frag(const float *lds, int row, int kbase)
 // cycles of MFMA.  (hipcc on its own sinks every read group next to its use: `ds_read; s_waitcnt lgkmcnt(0);
 // 4 x mfma`, which leaves the matrix pipe idle for the LDS round trip 16 times per k-tile.)  The
 // sched_group_barriers pin that order: the DS reads of the next slice, then the MFMAs of this one.
+#ifndef TCL_GEMM_SETPRIO
+#define TCL_GEMM_SETPRIO 2   // wave priority during the MFMA phase of gemm_f32_kernel (0 = leave it alone)
+#endif
 #ifndef TCL_GEMM_ABL
 #define TCL_GEMM_ABL 0   // timing ablations of side builds (wrong results): 1 no barriers, 2 no LDS stores, 4 no global loads in the loop, 8 no LDS reads
 #endif
@@ -756,6 +759,10 @@ __global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? ((BM 
         lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BK, g.N, g.K, tid);
       }
     }
+    // Raised wave priority while a wave multiplies (back to 0 for its staging): 1.3 % more cycles, but on the boxes that
+    // throttle this kernel (2.22 GHz instead of 2.40) the clock only drops to 2.31-2.34 GHz: 1.06 -> 1.005 ms
+    // there, 0.943 -> 0.955 ms on an unthrottled box.  -DTCL_GEMM_SETPRIO=0 switches it off.
+    if (TCL_GEMM_SETPRIO > 0) __builtin_amdgcn_s_setprio(TCL_GEMM_SETPRIO);
     if constexpr (IL) {
       mma_ktile_kmajor_il<BM, BN, WM, WN, BK, FIRST>(As, Bs, acc, wid, lr, lh);
     } else if (PIPE) {
@@ -779,6 +786,7 @@ __global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? ((BM 
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], FIRST && kg == 0 && e == 0 ? zero : acc[i][j], 0, 0, 0);   // transposed tile, see the epilogues
           }
     }
+    if (TCL_GEMM_SETPRIO > 0) __builtin_amdgcn_s_setprio(0);
     if (!(TCL_GEMM_ABL & 1)) __syncthreads();
   };
   ktile(std::true_type{}, 0);   // peeled: its MFMAs start from an inline zero
