@@ -198,6 +198,22 @@ def test_corr4d_properties_full_size(mods):
     assert torch.equal(out[0][vis[0] == 0], torch.zeros_like(out[0][vis[0] == 0]))
 
 
+def test_corr4d_backward_is_deterministic_at_c2(mods):
+    """No atomics and a fixed summation order in every contraction kernel: two runs at the C2 batch (the wide backward kernels,
+    256 blocks on 256 CUs) give bit-identical volumes and gradients."""
+    g = torch.Generator(device="cpu").manual_seed(12)
+    B, C, F, S = 16, 256, 1, 64
+    xt = torch.randn(B, C, S, S, generator=g).to(DEV).requires_grad_(True)
+    xr = torch.randn(B, C, F, S, S, generator=g).to(DEV).requires_grad_(True)
+    cot = torch.randn(B, F, S, S, S, S, generator=g).to(DEV)
+    runs = []
+    for _ in range(2):
+        out = mods["corr"].compute_masked_4d_correlation(xt, None, xr, None)
+        runs.append((out.detach().clone(),) + tuple(t.clone() for t in torch.autograd.grad(out, [xt, xr], grad_outputs=cot)))
+    for a, b, what in zip(runs[0], runs[1], ("volume", "g_x_t", "g_x_r")):
+        assert torch.equal(a, b), what
+
+
 def test_corr4d_c2_full_batch_vs_torch_fp32(mods):
     """BASELINE configs[1] at its full size (16 pairs, C = 256, 64 x 64): the shape bench.py times, i.e. the 128 x 128 forward
     kernel on 16,384 tiles and the wide backward kernels on 256.  Too large for the numpy oracle in a test, so the reference
