@@ -428,6 +428,9 @@ __device__ __forceinline__ f32x4 read_frag(const float *lds, int row, int kbase)
 // cycles of MFMA.  (hipcc on its own sinks every read group next to its use: `ds_read; s_waitcnt lgkmcnt(0);
 // 4 x mfma`, which leaves the matrix pipe idle for the LDS round trip 16 times per k-tile.)  The
 // sched_group_barriers pin that order: the DS reads of the next slice, then the MFMAs of this one.
+#ifndef TCL_GEMM_EPI_AUX
+#define TCL_GEMM_EPI_AUX 2   // cache policy of the epilogues' buffer stores: 2 = non-temporal
+#endif
 #ifndef TCL_GEMM_SETPRIO
 #define TCL_GEMM_SETPRIO 2   // wave priority during the MFMA phase of gemm_f32_kernel (0 = leave it alone)
 #endif
@@ -536,7 +539,7 @@ __device__ __forceinline__ void store_tile_il(f32x16 (&acc)[2][2], float *stg, c
     for (int k = 0; k < 8; ++k) {
       const int l = 8 * (k & 3) + rrow;   // staged row rrow + 8 k = wave row (k >> 2), l
       const f32x4 val = *reinterpret_cast<const f32x4 *>(stg + ((k >> 2) * 32 + l) * 128 + ((rc4 * 4) ^ (l << 2)));
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, voff, ((k >> 2) * 64 + 16 * (k & 3) + i) * d_ld4, 2 /* nt */);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, voff, ((k >> 2) * 64 + 16 * (k & 3) + i) * d_ld4, TCL_GEMM_EPI_AUX /* 2 = nt */);
     }
   }
 }
@@ -634,7 +637,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const f32x4 val = *reinterpret_cast<const f32x4 *>(smem + rd_off + k * (NT / (WN * 8)) * ELD);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, st_off[k], pass_off, 2 /* nt */);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, st_off[k], pass_off, TCL_GEMM_EPI_AUX /* 2 = nt */);
         }
       }
     return;
@@ -1089,7 +1092,7 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
         const f32x4 val = *reinterpret_cast<const f32x4 *>(stg + ((k >> 3) * 32 + l) * BN + ((rc4 * 4) ^ (l << 2)));
         const int voff = rrow * row_bytes + rc4 * 16;
         const int soff = (k >> 3) * (BM / WM) * d_ld4 + 4 * (k & 7) * row_bytes + (AQ ? i : i * 32) * d_ld4;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, voff, soff, 2 /* nt */);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, voff, soff, TCL_GEMM_EPI_AUX /* 2 = nt */);
       }
     }
   };
