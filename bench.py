@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: BASELINE.json's metric, aligned frame-pairs/sec through corr + warp + match, forward and backward.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU, under torch.distributed.run or, without a
+                                                            launcher, as N child processes this script starts itself)
 
 One pass of the hot path takes PAIRS_PER_PASS = 640 synthetic frame pairs per GPU (inputs resident in HBM) through the three
 legs, each at the shape its BASELINE config names, through the drop-in functions and the C ABI:
@@ -382,6 +383,30 @@ def cpu_baseline(budget_s=24.0):
 
 
 # ------------------------------------------------------------------------------------------------ main
+def launch_ranks(n):
+    """`python bench.py --gpus N` without torch.distributed.run: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, one per GPU) BEFORE this process makes any GPU call, pass rank 0's JSON line through and
+    return the worst exit code.  The parent never initialises the GPU and replaces no running program."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -393,11 +418,25 @@ def main():
     ap.add_argument("--legs-only", default="", help="development: only the cache-cold measurements of these groups (corr,warp,c4), one line per leg")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))   # no launcher around us: start the ranks ourselves (nothing has touched the GPU yet)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:   # the line must never carry an n_gpus the caller did not ask for
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("TCL_BENCH_DRY") == "1":
+        # launch-plumbing check for boxes without a GPU (tests/test_parallel.py): rendezvous over gloo, count the ranks, print a
+        # line that carries no measurement
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        n = torch.ones(1, dtype=torch.int64)
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.all_reduce(n)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "dry_run": True, "n_gpus": world, "ranks_seen": int(n.item())}), flush=True)
+        return
     # rehearsal switch (not used by the driver): TCL_BENCH_REHEARSE=1 runs every rank on GPU 0 with gloo for the barrier /
     # max-over-ranks, so the N > 1 code path can be exercised on a one-GPU box
     rehearse = os.environ.get("TCL_BENCH_REHEARSE") == "1"

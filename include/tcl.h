@@ -13,7 +13,10 @@
  *    shape written next to them; "nullable" pointers may be NULL;
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call only enqueues
  *    work on `stream`: it never synchronises, never allocates or frees device memory and keeps no
- *    mutable global state (re-entrant across streams and across the per-GPU processes);
+ *    mutable state that results depend on (re-entrant across streams and across the per-GPU processes).
+ *    The only process-wide state is two per-device lookup caches, each filled once under a mutex: the
+ *    kernel attribute + CU count of the wide contraction kernels (tcl_corr4d_bwd) and the device address
+ *    of the static scratch array of tcl_ctx_fwd_static;
  *  - scratch space is a caller-provided `workspace` whose size comes from the matching
  *    *_workspace_bytes function; it must be 256-byte aligned;
  *  - return value: TCL_OK (0) or a TCL_ERR_* code; tcl_last_error() then returns a thread-local,

@@ -102,7 +102,11 @@ def corr4d(x_t, v_t, x_r, v_r, precision=None):
     a build extension selected by input dtype") -> the bf16-MFMA variant with fp32 accumulation, result in the input dtype
     (what torch.matmul of the reference returns for such inputs)."""
     low = x_r.dtype in (torch.bfloat16, torch.float16) and not torch.is_autocast_enabled("cuda")
+    if not torch.is_autocast_enabled("cuda") and x_t.dtype != x_r.dtype:
+        raise TclError("x_target_feats (%s) and x_ref_feats (%s) must share a dtype" % (x_t.dtype, x_r.dtype))
     if low:
+        # fp16 tensors take the same bf16-operand path (8-bit mantissa, 1e-2 bar: coarser than an fp16 matmul, documented in
+        # DESIGN.md section 1); the fp32 accumulator is rounded to the input dtype on the way out
         in_dtype = x_r.dtype
         f32 = lambda t: None if t is None else t.float()
         out = Corr4dFn.apply(f32(x_t), f32(v_t), f32(x_r), f32(v_r), _lib.PREC_BF16 if precision is None else precision)

@@ -1158,13 +1158,15 @@ static int launch_gemm_wide(GemmArgs g, int cus, hipStream_t s, const char *what
   return check_launch(what);
 }
 // the wide kernel wants whole 256 x 256 x 64 tiles, 16-byte aligned rows and enough tiles to give most CUs one
-static bool gemm_wide_ok(const GemmArgs &g) {
+static bool gemm_wide_ok(const GemmArgs &g, bool a_kc, bool b_kc) {
   const bool vec = aligned(g.A, 16) && aligned(g.B, 16) && aligned(g.D, 16) && g.a_ld % 4 == 0 && g.b_ld % 4 == 0 && g.d_ld % 4 == 0 &&
                    g.a_bs % 4 == 0 && g.b_bs % 4 == 0 && g.d_bs % 4 == 0 && g.a_ss % 4 == 0 && g.b_ss % 4 == 0;
   // K % 64: an even number of k-tiles per output tile (the k-loop is unrolled over the two LDS stages); the byte offsets of
-  // one output tile's operand panels (rows x ld, all segments) are kept in 31 bits (buffer loads: 32-bit voffset + soffset)
+  // one output tile's operand panels (rows x ld for a k-contiguous operand, K x ld for a k-major one, all segments) are kept
+  // in 31 bits (buffer loads: 32-bit voffset + soffset; beyond num_records a raw buffer load silently returns 0)
   return vec && g.M % 256 == 0 && g.N % 256 == 0 && g.K % (2 * BK) == 0 && g.a_ld < (1 << 21) && g.b_ld < (1 << 21) &&
-         (int64_t)g.nseg * g.a_ss * 4 + 256 * g.a_ld * 4 < (1LL << 31) && (int64_t)g.nseg * g.b_ss * 4 + 256 * g.b_ld * 4 < (1LL << 31) &&
+         (int64_t)g.nseg * g.a_ss * 4 + (int64_t)(a_kc ? 256 : g.K) * g.a_ld * 4 < (1LL << 31) &&
+         (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(b_kc ? 256 : g.K) * g.b_ld * 4 < (1LL << 31) &&
          (int64_t)256 * g.d_ld * 4 < (1LL << 31) && (int64_t)(g.M / 256) * (g.N / 256) * g.nbatch >= 128;
 }
 
@@ -1758,7 +1760,7 @@ extern "C" int tcl_corr4d_contract(const void *fwd_workspace, float *out, int64_
 #define TCL_FWD_TILE 128, 128, 2, 2
 #endif
 #ifdef TCL_GEMM_WIDE_FWD
-  if (gemm_wide_ok(g))
+  if (gemm_wide_ok(g, false, false))
     if (const int cus = wide_kernel_ready<false, false, true>()) return launch_gemm_wide<false, false, true>(g, cus, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
 #endif
   return launch_gemm<TCL_FWD_TILE, false, false>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
@@ -1835,7 +1837,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_ss = C * P; g.b_ss = P * P; g.a_bdiv = 1; g.nbatch = (int)B;
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, true>(g, nsplit, s, "tcl_corr4d_bwd(d_a bf16 gemm)");
 #ifndef TCL_GEMM_NO_WIDE
-    else if (gemm_wide_ok(g) && wide_kernel_ready<true, true, false>()) rc = launch_gemm_wide<true, true, false>(g, 0, s, "tcl_corr4d_bwd(d_a gemm)");
+    else if (gemm_wide_ok(g, true, true) && wide_kernel_ready<true, true, false>()) rc = launch_gemm_wide<true, true, false>(g, 0, s, "tcl_corr4d_bwd(d_a gemm)");
 #endif
     else rc = launch_gemm<256, 128, 4, 2, true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
     if (rc) return rc;
@@ -1853,7 +1855,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, false>(g, nsplit, s, "tcl_corr4d_bwd(d_r bf16 gemm)");
 #ifndef TCL_GEMM_NO_WIDE
-    else if (gemm_wide_ok(g) && wide_kernel_ready<true, false, false>()) rc = launch_gemm_wide<true, false, false>(g, 0, s, "tcl_corr4d_bwd(d_r gemm)");
+    else if (gemm_wide_ok(g, true, false) && wide_kernel_ready<true, false, false>()) rc = launch_gemm_wide<true, false, false>(g, 0, s, "tcl_corr4d_bwd(d_r gemm)");
 #endif
     else rc = launch_gemm<256, 128, 4, 2, true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
     if (rc) return rc;

@@ -409,7 +409,9 @@ __device__ __forceinline__ void emit_row_aligned(float *gbase, int64_t sc, int W
   // Downscaling flows: two neighbouring lanes with the SAME tap.  The second lane of such a pair takes the first one's values
   // (one pass: pairs only; the third lane of a longer run loses the push below and adds at its own address).
   {
-    const int key = todo ? off : 0x7fffffff - lane;                  // distinct for idle lanes
+    // the key is the PAIR (r, xi), not the flat offset: (r, -1) and (r - 1, W - 1) share an offset but are different taps
+    // (one has only an east column, the other only a west one); r, xi + 1 < 2^14 on this path
+    const int key = todo ? ((r << 15) | (xi + 1)) : 0x7fffffff - lane;   // distinct for idle lanes
     const int k1 = __shfl_up(key, 1, 64), k2 = __shfl_up(key, 2, 64), kd = __shfl_down(key, 1, 64);
     const bool take = todo & (lane >= 1) & (k1 == key) & ((lane < 2) | (k2 != key));   // lane - 1 heads a run that I continue
     const bool give = todo & (lane < 63) & (kd == key) & ((lane < 1) | (k1 != key));   // I head a run and lane + 1 takes me

@@ -156,8 +156,10 @@ class Runner:
         torch.save(data, self.experiment.checkpoint_path(self.counters["epoch"]))
 
     def load_states(self, epoch, device):
-        # files this module wrote itself; tensors + plain containers only
-        data = torch.load(self.experiment.checkpoint_path(epoch), map_location=device, weights_only=False)
+        # everything save_states writes is tensors + plain containers (state_dicts, counters, float dicts): the weights-only loader
+        # reads it and executes nothing from the file (a checkpoint dropped into the experiment directory cannot run code); a
+        # subclass whose save_states_others adds another type allow-lists it with torch.serialization.add_safe_globals
+        data = torch.load(self.experiment.checkpoint_path(epoch), map_location=device, weights_only=True)
         self.model.load_state_dict(data["model"])
         self.optimizer.load_state_dict(data["optimizer"])
         self.counters, self.losses_epoch = dict(data["counters"]), data["losses_epoch"]

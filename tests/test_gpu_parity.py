@@ -484,6 +484,34 @@ def test_warp_tiled_backward_smooth_flows(C, H, W, scale, rot, jitter):
     assert_close(N(gth), O.affine_grid_bwd(ogg, H, W, False), what="g_theta")
 
 
+def test_warp_tiled_backward_wraparound_taps():
+    """neighbouring lanes whose taps share a flat offset but not a (row, column): lane l samples (row r, x in [-1, 0))
+    (only its east column is inside the image) and lane l + 1 samples (row r - 1, x in [W - 1, W)) (only its west column is).
+    The duplicate-tap pre-merge of the tiled backward must not treat them as the same tap."""
+    from master_thesis_amd import _lib, _ops
+    rng = np.random.default_rng(77)
+    B, C, F, H, W = 1, 3, 2, 32, 64
+    x = rng.random((B, C, F, H, W)).astype(np.float32)
+    cot = rng.standard_normal((B, C, F, H, W)).astype(np.float32)
+    ix = np.empty((F, H, W), np.float32)
+    iy = np.empty((F, H, W), np.float32)
+    rows = (np.arange(H) % (H - 2) + 1).astype(np.float32)[None, :, None]        # r in [1, H - 2]
+    even = (np.arange(W) % 2 == 0)[None, None, :]
+    ix[:] = np.where(even, -0.4, W - 1 + 0.3)
+    iy[:] = np.where(even, rows + 0.3, rows - 1 + 0.3)
+    ix[1] = np.where(even[0], W - 1 + 0.6, -0.7)                                  # frame 1: the pair the other way round
+    iy[1] = np.where(even[0], rows[0] - 1 + 0.5, rows[0] + 0.5)
+    flow = np.stack([2 * ix / (W - 1) - 1, 2 * iy / (H - 1) - 1], -1).astype(np.float32)
+    tx_, tf = T(x, True), T(flow, True)
+    xa, _ = _ops.WarpFn.apply(tx_, None, tf, None, True, _lib.VMODE_NONE)
+    gx, gf = torch.autograd.grad((xa * T(cot)).sum(), [tx_, tf])
+    src = x.transpose(0, 2, 1, 3, 4).reshape(B * F, C, H, W)
+    ogx, ogf = O.grid_sample_bilinear_bwd(src, flow, True, cot.transpose(0, 2, 1, 3, 4).reshape(B * F, C, H, W))
+    assert float(np.abs(ogx[:, :, :, 0]).max()) > 0 and float(np.abs(ogx[:, :, :, W - 1]).max()) > 0
+    assert_close(N(gx).transpose(0, 2, 1, 3, 4).reshape(B * F, C, H, W), ogx, what="g_x (wrap-around taps)")
+    assert_close(N(gf), ogf, what="g_grid (wrap-around taps)")
+
+
 def test_warp_many_large_frames_one_launch():
     """200 frames of 300 x 300 = 352 chunks x 200 frames > 65535, each frame with its own source (gf == 1): the
     forward used to reject what the backward accepts."""
@@ -705,7 +733,7 @@ def test_context_matching_properties_full_size(mods):
     assert float(p1[:, C:2 * C].permute(0, 2, 3, 1)[none].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("frames", [[0, 1, 3, 4], [2], [4, 0, 1], [0, 2, 4, 1, 3], [1, 2, 3]])
+@pytest.mark.parametrize("frames", [[0, 1, 3, 4], [2], [4, 0, 1], [0, 2, 4, 1, 3], [1, 2, 3], [1, 1, 3]])
 @pytest.mark.parametrize("use_theta", [True, False])
 def test_warp_frames_equals_gathered_frames(mods, frames, use_theta):
     """WarpFn(x, ..., frames=r_list) (reference frames read in place, one launch per run of consecutive indices; more than

@@ -182,3 +182,37 @@ def test_gradient_buckets_overlap_survives_dropped_views():
             assert torch.allclose(p.grad, r, rtol=1e-6, atol=1e-7)
         assert torch.equal(unused.grad, torch.zeros(3))
         assert all(any(f.data_ptr() <= p.grad.data_ptr() < f.data_ptr() + 4 * f.numel() for f in gb._flat) for p in params)
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr.decode()
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run must start two ranks itself (and say n_gpus 2), never
+    measure one GPU under the label N.  Dry mode: gloo rendezvous only, no GPU, no measurement in the line."""
+    rc, lines, err = _run_bench(["--gpus", "2"], {"TCL_BENCH_DRY": "1"})
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2 and lines[0]["value"] is None
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    rc, lines, err = _run_bench(["--gpus", "1"], {"TCL_BENCH_DRY": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and not lines and "WORLD_SIZE" in err
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The real N = 2 path of bench.py (barrier, max over ranks, whole-job value) with both ranks on GPU 0 and gloo."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "2", "--no-legs", "--no-variants", "--no-cpu-baseline"],
+                                {"TCL_BENCH_REHEARSE": "1"}, timeout=600)
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0 and lines[0]["scaling"] == "weak"
