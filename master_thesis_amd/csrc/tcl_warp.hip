@@ -180,12 +180,39 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
   }
 }
 
+// The value lane + 1 holds (DPP wave shift: a register-to-register move, no LDS); lane 63 gets 0.
+__device__ __forceinline__ int lane_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ float lane_next(float v) { return __int_as_float(lane_next(__float_as_int(v))); }
+
+// The taps of one plane: west column of the north / south row by one 4-byte load each; the EAST column comes from lane + 1
+// when that lane's west taps are this lane's east taps (same two rows, next column: the common case of a smooth flow, where
+// neighbouring output pixels sample neighbouring source columns), else from a second load that only the remaining lanes
+// issue (lane 63, the lanes where the sampled row changes, columns an upscaling flow skips).  Against the two unaligned
+// 8-byte gathers per plane this halves the bytes the vector L1 / texture addresser returns per pixel; the values are the
+// same memory words either way, so results are bit-identical.
+struct ShareTaps {
+  unsigned on_w, os_w, on_e, os_e;   // element offsets inside a plane: (north | south row, west | east column), always inside the image
+  bool share;
+};
+__device__ __forceinline__ ShareTaps make_share(const Taps &t, int W, bool live) {
+  ShareTaps s;
+  const int cw = max(0, min(t.xi, W - 1)), ce = max(0, min(t.xi + 1, W - 1));
+  s.on_w = (unsigned)(t.ya * W + cw); s.os_w = (unsigned)(t.yb * W + cw);
+  s.on_e = (unsigned)(t.ya * W + ce); s.os_e = (unsigned)(t.yb * W + ce);
+  const unsigned nn = (unsigned)lane_next((int)s.on_w), ns = (unsigned)lane_next((int)s.os_w);
+  s.share = ((threadIdx.x & 63) < 63) & (nn == s.on_e) & (ns == s.os_e);
+  (void)live;
+  return s;
+}
+struct PlaneTaps { float nw, ne, sw, se; };
+
 template <bool HAS_THETA, bool W2, int VMODE, bool C3>
 __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chunk) {
   const int H = a.H, W = a.W;
   const int b = (int)a.fd_nf.div((unsigned)n), f = n - b * a.NF;
-  const int pix = chunk * 256 + threadIdx.x;   // flattened: every wave reads / writes 256 contiguous, aligned bytes per plane
-  if (pix >= H * W) return;
+  const int pix0 = chunk * 256 + threadIdx.x;   // flattened: every wave reads / writes 256 contiguous, aligned bytes per plane
+  const bool ok = pix0 < H * W;
+  const int pix = ok ? pix0 : H * W - 1;        // lanes past the image repeat its last pixel (they take part in the lane exchanges), store nothing
   const int y = (int)a.fd_w.div((unsigned)pix), x = pix - y * W;
   const bool ac = a.align_corners != 0;
   float gx, gy;
@@ -203,6 +230,50 @@ __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chun
   const float *vp = a.v + b * a.v_sb + f * a.v_sf;
   const float *xp = a.x + b * a.x_sb + f * a.x_sf;
   float *op = a.xo + b * a.xo_sb + f * a.xo_sf + pix;
+  // Measured (round 3, cache-cold legs, A/B in the same runs): align_set (grid source, nearest visibility) 65.8 -> 63.9 us with
+  // the shared taps; the affine forward (theta source, bilinear visibility: 8 west + 8 masked east loads instead of 8 gathers)
+  // 0.261 -> 0.308 ms, i.e. that kernel pays per vector-memory INSTRUCTION, not per byte the L1 returns.  So: grid sources only.
+#ifndef TCL_WARP_FWD_NO_SHARE
+  if (C3 && !HAS_THETA) {
+    // ---- west taps of every plane (unconditional), then the east taps of the lanes that cannot take them from lane + 1
+    constexpr bool VB = VMODE == TCL_VMODE_BILINEAR_THRESHOLD;
+    constexpr int NP = VB ? 4 : 3;
+    const ShareTaps s = make_share(t, W, ok);
+    const float *pl[4] = {xp, xp + a.x_sc, xp + 2 * a.x_sc, vp};
+    float wn[NP], ws[NP], en[NP], es[NP];
+    float vnear = 0.f;
+    bool inb = false;
+    if (VMODE == TCL_VMODE_NEAREST) {
+      const float xn = rintf(ix), yn = rintf(iy);  // v_rndne: half to even, as std::nearbyint
+      inb = (xn >= 0.f) & (xn <= (float)(W - 1)) & (yn >= 0.f) & (yn <= (float)(H - 1));
+      vnear = vp[(inb ? (int)yn : 0) * W + (inb ? (int)xn : 0)];   // unconditional load, then select
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { wn[p] = pl[p][s.on_w]; ws[p] = pl[p][s.os_w]; en[p] = 0.f; es[p] = 0.f; }
+    if (!s.share) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { en[p] = pl[p][s.on_e]; es[p] = pl[p][s.os_e]; }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const float nn = lane_next(wn[p]), ns = lane_next(ws[p]);
+      en[p] = s.share ? nn : en[p];
+      es[p] = s.share ? ns : es[p];
+    }
+    if (VMODE == TCL_VMODE_NEAREST) { if (ok) st_stream(a.vo + b * a.vo_sb + f * a.vo_sf + pix, inb ? vnear : 0.f); }
+    else if (VB) {
+      const float vr = blend((t.yn & t.xw) ? wn[3] : 0.f, (t.yn & t.xe) ? en[3] : 0.f, (t.ys & t.xw) ? ws[3] : 0.f, (t.ys & t.xe) ? es[3] : 0.f, t);
+      if (ok) st_stream(a.vo + b * a.vo_sb + f * a.vo_sf + pix, vr > 0.5f ? 1.f : 0.f);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float val = blend((t.yn & t.xw) ? wn[c] : 0.f, (t.yn & t.xe) ? en[c] : 0.f, (t.ys & t.xw) ? ws[c] : 0.f, (t.ys & t.xe) ? es[c] : 0.f, t);
+      if (ok) st_stream(op + c * a.xo_sc, val);
+    }
+    return;
+  }
+#endif
+  if (!ok) return;
   // ---- loads
   float vnear = 0.f;
   bool inb = false;
@@ -271,11 +342,13 @@ struct WarpBwdArgs {
 template <bool HAS_THETA, bool HAS_GX, bool W2, bool C3>
 __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
   const int H = a.H, W = a.W, HW = H * W, nchunk = (HW + 255) >> 8;
-#ifdef TCL_WARP_BWD_XCD   // A/B switch: the forward's XCD-aware order makes no difference here (64.5 vs 65.2 us per launch)
+  // the forward's (XCD, chunk, image / 8) order: one XCD walks one image, so the source rows that neighbouring chunks share are
+  // fetched into ONE L2 (round 2 measured 1.28x the algorithmic bytes with the (chunk, image) grid, at the same speed)
+#ifdef TCL_WARP_BWD_NO_XCD   // A/B switch: the round-2 grid
+  const int n = blockIdx.y, chunk = blockIdx.x;
+#else
   int n, chunk;
   if (!warp_block(nchunk, 1, a.NB * a.NF, n, chunk)) return;
-#else
-  const int n = blockIdx.y, chunk = blockIdx.x;
 #endif
   const int b = (int)a.fd_nf.div((unsigned)n), f = n - b * a.NF;
   const int pix0 = chunk * 256 + threadIdx.x;
@@ -472,7 +545,12 @@ template <bool HAS_THETA, bool HAS_GX, bool C3>
 __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int tiles_x, int tiles_y) {
   __shared__ float red[4][6];
   const int H = a.H, W = a.W, HW = H * W;
+#ifdef TCL_WARP_BWD_NO_XCD
   const int n = blockIdx.y, tile = blockIdx.x;
+#else
+  int n, tile;   // (XCD, tile, image / 8): an image's tiles, which share source rows and columns, stay on one XCD's L2
+  if (!warp_block(tiles_x * tiles_y, 1, a.NB * a.NF, n, tile)) return;
+#endif
   const int trow = tile / tiles_x;
   const int lx = threadIdx.x & 63, ly = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ty0 = trow * TILE_H + ly * TILE_K, tx0 = (tile - trow * tiles_x) * TILE_W;   // this wave's strip: rows ty0 .. ty0 + TILE_K - 1
@@ -701,7 +779,7 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
   TCL_REQUIRE(!(grid && g_theta) && !(theta && g_grid), TCL_ERR_ARG, "tcl_warp_bwd: gradient kind does not match the forward's source");
   TCL_REQUIRE(!grid || aligned(grid, 8), TCL_ERR_ARG, "tcl_warp_bwd: grid must be 8-byte aligned");
   TCL_REQUIRE(!g_grid || aligned(g_grid, 8), TCL_ERR_ARG, "tcl_warp_bwd: g_grid must be 8-byte aligned");
-  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536, TCL_ERR_SHAPE,
+  TCL_REQUIRE(H * W < (1LL << 30) && NB * NF < 65536 && cdiv(H * W, 256) < 65536, TCL_ERR_SHAPE,
               "tcl_warp_bwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   if (!g_x && !g_grid && !g_theta) return TCL_OK;
   const int N = (int)(NB * NF);
@@ -717,10 +795,10 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
                 g_grid, partial, (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, lin_step(W), lin_step(H),
                 make_fastdiv((uint32_t)W), make_fastdiv((uint32_t)NF)};
   hipStream_t s = (hipStream_t)stream;
-#ifdef TCL_WARP_BWD_XCD
-  const dim3 grd = warp_grid(per, 1, N), blk(256);
-#else
+#ifdef TCL_WARP_BWD_NO_XCD
   const dim3 grd((unsigned)per, (unsigned)N), blk(256);
+#else
+  const dim3 grd = warp_grid(per, 1, N), blk(256);
 #endif
 #define TCL_LAUNCH_WBWD(TH, GX)                                                                   \
   do {                                                                                             \
@@ -739,7 +817,11 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
   if (tiled) {
     const int tx = (int)cdiv(W, TILE_W), ty = (int)cdiv(H, TILE_H);
     nblk = tx * ty;   // <= cdiv(H * W, 256) for H >= 32, W >= 64: the theta workspace is large enough
+#ifdef TCL_WARP_BWD_NO_XCD
     const dim3 tg((unsigned)nblk, (unsigned)N);
+#else
+    const dim3 tg = warp_grid(nblk, 1, N);
+#endif
 #define TCL_LAUNCH_WTILE(TH, GX)                                                                          \
   do {                                                                                                     \
     if (C == 3) hipLaunchKernelGGL((warp_bwd_tile_kernel<TH, GX, true>), tg, blk, 0, s, a, tx, ty);        \
