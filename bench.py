@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 # peaks: /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 PEAK_F32_MATRIX_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA
 
 METRIC = "aligned frame-pairs/sec (corr+warp+match fwd+bwd) at 1/2/4/8 GPUs; % roofline"
 PAIRS_PER_PASS = 640
@@ -154,12 +155,12 @@ def measure_legs(dev, corr, warp_sets, c4_sets, groups=("corr", "warp", "c4")):
     sp = ctypes.c_void_p(stream.cuda_stream)
     legs = {}
 
-    def add(name, kernel, ms, nbytes=None, flops=None, note=None):
+    def add(name, kernel, ms, nbytes=None, flops=None, note=None, peak_tf=PEAK_F32_MATRIX_TFLOPS):
         r = {"kernel": kernel, "ms_per_launch": round(ms, 4)}
         if flops is not None:
             tf = flops / (ms * 1e-3) / 1e12
-            r.update(bound="mfma", algorithmic_flops=int(flops), achieved=round(tf, 2), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
-                     frac=round(tf / PEAK_F32_MATRIX_TFLOPS, 4))
+            r.update(bound="mfma", algorithmic_flops=int(flops), achieved=round(tf, 2), peak=peak_tf, unit="TFLOP/s",
+                     frac=round(tf / peak_tf, 4))
         else:
             gbs = nbytes / (ms * 1e-3) / 1e9
             r.update(bound="hbm", algorithmic_bytes=int(nbytes), achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
@@ -194,9 +195,29 @@ def _legs_corr(dev, corr, add, lib, stream, sp):
     ms = time_rotating([lambda: _lib.call("tcl_corr4d_contract", _p(ws), _p(out), B, C, F, P, 0, sp)], stream, rounds=40, warm=80)
     add("corr_fwd_contraction", "gemm_f32_kernel<128,128,2,2,...,FULL> (tcl_corr4d_contract)", ms, flops=flops)
     for prec, name in ((2, "bf16x3"), (1, "bf16")):
-        ms = time_rotating([lambda: _lib.call("tcl_corr4d_contract", _p(ws), _p(out), B, C, F, P, prec, sp)], stream, rounds=20, warm=3)
-        add("corr_fwd_contraction_" + name, "gemm_bf16_kernel<128,128,2,2,NS=%d> (variant, not the headline)" % (2 if prec == 2 else 1), ms,
-            nbytes=B * F * P * P * 4 + (B + B * F) * C * P * 4, note="bound by the store of the fp32 volume (1 GiB per launch)")
+        # the variant's own forward first: its workspace holds the bf16 (hi, lo) operand images the contraction reads
+        wsv = torch.empty(lib.tcl_corr4d_fwd_workspace_bytes(B, C, F, P, prec), dtype=torch.uint8, device=dev)
+        _lib.call("tcl_corr4d_fwd", _p(xt), _p(vt), _p(xr), _p(vr), _p(out), B, C, F, P, prec, _p(wsv), wsv.numel(), sp)
+        ms = time_rotating([lambda: _lib.call("tcl_corr4d_contract", _p(wsv), _p(out), B, C, F, P, prec, sp)], stream, rounds=20, warm=3)
+        nsl = 2 if prec == 2 else 1
+        add("corr_fwd_contraction_" + name, "gemm_bf16op_kernel<128,128,2,2,NS=%d> (variant, not the headline)" % nsl, ms,
+            nbytes=B * F * P * P * 4 + (B + B * F) * C * P * 2 * nsl, note="bound by the store of the fp32 volume (1 GiB per launch); bf16 operand images")
+        # N1: the same contraction fused with corr_to_flow: no volume, bound by the bf16 matrix pipe
+        wsa = torch.empty(lib.tcl_corr4d_argmax_flow_workspace_bytes(B, C, F, P, prec), dtype=torch.uint8, device=dev)
+        fl = torch.empty(B, F, P, 2, device=dev)
+        ms = time_rotating([lambda: _lib.call("tcl_corr4d_argmax_flow", _p(xt), _p(vt), _p(xr), _p(vr), _p(fl), B, C, F, S, prec, _p(wsa), wsa.numel(), sp)],
+                           stream, rounds=20, warm=20)
+        nm = 3 if prec == 2 else 1
+        add("corr_argmax_flow_" + name, "tcl_corr4d_argmax_flow(%s)" % name, ms, flops=flops * nm, peak_tf=PEAK_BF16_TFLOPS,
+            note="whole entry point: 2 x corr_normalise + gemm_bf16op_kernel<EPI_ARGMAX> + argmax_tiles_to_flow; flops = the bf16 MFMA flops "
+                 "issued (%d x the algorithmic 2 P P C), against the dense bf16 peak" % nm)
+        del wsv, wsa, fl
+    wsa = torch.empty(lib.tcl_corr4d_argmax_flow_workspace_bytes(B, C, F, P, 0), dtype=torch.uint8, device=dev)
+    fl = torch.empty(B, F, P, 2, device=dev)
+    ms = time_rotating([lambda: _lib.call("tcl_corr4d_argmax_flow", _p(xt), _p(vt), _p(xr), _p(vr), _p(fl), B, C, F, S, 0, _p(wsa), wsa.numel(), sp)],
+                       stream, rounds=20, warm=40)
+    add("corr_argmax_flow_f32", "tcl_corr4d_argmax_flow(f32)", ms, flops=flops, note="2 x corr_normalise + gemm_f32_kernel<EPI_ARGMAX> + argmax_tiles_to_flow")
+    del wsa, fl
     ms = time_rotating([lambda: _lib.call("tcl_corr4d_bwd", _p(cot), _p(xt), _p(vt), _p(xr), _p(vr), _p(ws), _p(gt), _p(gr), B, C, F, P, 0,
                                           _p(ws2), ws2.numel(), sp)], stream, rounds=20, warm=40)
     add("corr_bwd", "2 x gemm_f32_wide_kernel (256x256 tiles) + corr_normalise_bwd (tcl_corr4d_bwd)", ms, flops=2 * flops)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TCL_VERSION 100
+#define TCL_VERSION 110
 
 enum {
   TCL_OK = 0,
@@ -74,8 +74,9 @@ const char *tcl_last_error(void);
  *     utils/correlation.py:28-54.
  *   x_t (B,C,P)  v_t (B,P) nullable   x_r (B,C,F,P)  v_r (B,F,P) nullable   P = H*W
  *   out (B,F,P,P): out[b,f,p,q] = <a^[b,:,p], r^[b,f,:,q]>, a^ = x v / (||x v||_2 + 1e-9).
- *   The forward leaves the normalised operands and the norms in `workspace`; pass the same buffer,
- *   unmodified, to tcl_corr4d_bwd as `fwd_workspace`.
+ *   The forward leaves the normalised operands and the norms in `workspace` (fp32 images in every variant; the bf16
+ *   variants add the bf16 (hi, lo) images their contraction reads); pass the same buffer, unmodified, to tcl_corr4d_bwd
+ *   as `fwd_workspace`.
  * ------------------------------------------------------------------------------------------- */
 size_t tcl_corr4d_fwd_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P, int precision);
 int tcl_corr4d_fwd(const float *x_t, const float *v_t, const float *x_r, const float *v_r, float *out,
@@ -97,10 +98,13 @@ int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const float *v_t, co
                    void *workspace, size_t workspace_bytes, void *stream);
 
 /* A1 + A10 fused: corr_to_flow(compute_masked_4d_correlation(...)) without the volume in HBM.
- *   flow (B,F,P,2), utils/flow.py:8-26 on top of utils/correlation.py:28-54.  S = side of the square map (P = S*S). */
-size_t tcl_corr4d_argmax_flow_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P);
+ *   flow (B,F,P,2), utils/flow.py:8-26 on top of utils/correlation.py:28-54.  S = side of the square map (P = S*S).
+ *   `precision` as in tcl_corr4d_fwd: with TCL_PREC_BF16 / BF16X3 the contraction runs on the bf16 matrix pipe and, with no
+ *   fp32 volume to store, is bound by that pipe and not by HBM; the indices then are the argmax of THAT precision's volume
+ *   (bit-identical to tcl_corr_to_flow over tcl_corr4d_fwd at the same precision). */
+size_t tcl_corr4d_argmax_flow_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P, int precision);
 int tcl_corr4d_argmax_flow(const float *x_t, const float *v_t, const float *x_r, const float *v_r, float *flow,
-                           int64_t B, int64_t C, int64_t F, int64_t S,
+                           int64_t B, int64_t C, int64_t F, int64_t S, int precision,
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

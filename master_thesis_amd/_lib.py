@@ -25,8 +25,8 @@ SIGNATURES = {
     "tcl_corr4d_contract": (_INT, [_P] * 2 + [_I64] * 4 + [_INT, _P]),
     "tcl_corr4d_bwd_workspace_bytes": (_SZ, [_I64] * 4 + [_INT]),
     "tcl_corr4d_bwd": (_INT, [_P] * 8 + [_I64] * 4 + [_INT, _P, _SZ, _P]),
-    "tcl_corr4d_argmax_flow_workspace_bytes": (_SZ, [_I64] * 4),
-    "tcl_corr4d_argmax_flow": (_INT, [_P] * 5 + [_I64] * 4 + [_P, _SZ, _P]),
+    "tcl_corr4d_argmax_flow_workspace_bytes": (_SZ, [_I64] * 4 + [_INT]),
+    "tcl_corr4d_argmax_flow": (_INT, [_P] * 5 + [_I64] * 4 + [_INT, _P, _SZ, _P]),
     "tcl_corr1x1_fwd": (_INT, [_P] * 5 + [_I64] * 3 + [_P]),
     "tcl_corr1x1_bwd": (_INT, [_P] * 7 + [_I64] * 3 + [_P]),
     "tcl_warp_fwd": (_INT, [_P, _I64, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _P, _I64, _I64]

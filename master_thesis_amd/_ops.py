@@ -114,20 +114,23 @@ def corr4d(x_t, v_t, x_r, v_r, precision=None):
     return Corr4dFn.apply(x_t, v_t, x_r, v_r, _lib.PREC_F32 if precision is None else precision)
 
 
-def corr4d_argmax_flow(x_t, v_t, x_r, v_r):
-    """corr_to_flow(compute_masked_4d_correlation(...)) without materialising the volume (square maps only)."""
+def corr4d_argmax_flow(x_t, v_t, x_r, v_r, precision=None):
+    """corr_to_flow(compute_masked_4d_correlation(...)) without materialising the volume (square maps only).  `precision`
+    (default fp32) selects the contraction's arithmetic as in corr4d: with bf16 / bf16x3 the fused kernel runs on the bf16
+    matrix pipe, unbound from the fp32 volume store."""
     dev = _require_device(x_t, v_t, x_r, v_r)
     b, c, f, h, w = x_r.shape
     if h != w:
         raise ValueError("corr_to_flow needs square feature maps (got %dx%d)" % (h, w))
     p = h * w
+    prec = _lib.PREC_F32 if precision is None else precision
     xt, xr = x_t.detach().contiguous(), x_r.detach().contiguous()
     vt = None if v_t is None else v_t.expand(b, 1, h, w).contiguous()
     vr = None if v_r is None else v_r.expand(b, 1, f, h, w).contiguous()
     flow = torch.empty((b, f, h, w, 2), dtype=torch.float32, device=dev)
-    ws = _workspace(_lib.lib().tcl_corr4d_argmax_flow_workspace_bytes(b, c, f, p), dev)
+    ws = _workspace(_lib.lib().tcl_corr4d_argmax_flow_workspace_bytes(b, c, f, p, prec), dev)
     with torch.cuda.device(dev):
-        _lib.call("tcl_corr4d_argmax_flow", _p(xt), _p(vt), _p(xr), _p(vr), _p(flow), b, c, f, h, _p(ws), ws.numel(), _stream(dev))
+        _lib.call("tcl_corr4d_argmax_flow", _p(xt), _p(vt), _p(xr), _p(vr), _p(flow), b, c, f, h, prec, _p(ws), ws.numel(), _stream(dev))
     return flow
 
 

@@ -24,6 +24,9 @@ namespace tcl {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------ normalise
 // x element (b,c,f,p) at ((b*C + c)*F + f)*P + p; v element (b,f,p); hat element ((b*F+f)*C + c)*P + p.
@@ -45,9 +48,34 @@ template <int PX> __device__ __forceinline__ void stv(float *p, const PxV<PX> &a
   else p[0] = a.v[0];
 }
 
+// Where the normalised operand goes (any subset, block-uniform): the fp32 image (exact-fp32 contraction, every backward
+// product), its bf16 rounding `hi` and the residual `lo` = bf16(x - hi) (TCL_PREC_BF16 / BF16X3: the contraction then reads
+// ready-made bf16 operands: no conversion instructions in its k-loop, half the operand bytes).  Same element order in all three.
+struct HatOut { float *f; __bf16 *hi, *lo; };
+template <int PX> __device__ __forceinline__ void st_hat(const HatOut &o, int64_t idx, const PxV<PX> &a) {
+  if (o.f) stv<PX>(o.f + idx, a);
+  if (o.hi) {
+    __bf16 h[PX], l[PX];
+#pragma unroll
+    for (int e = 0; e < PX; ++e) { h[e] = (__bf16)a.v[e]; l[e] = (__bf16)(a.v[e] - (float)h[e]); }
+    if (PX == 4) {
+      const bf16x4 hv = {h[0], h[1 % PX], h[2 % PX], h[3 % PX]}, lv = {l[0], l[1 % PX], l[2 % PX], l[3 % PX]};
+      *reinterpret_cast<bf16x4 *>(o.hi + idx) = hv;
+      if (o.lo) *reinterpret_cast<bf16x4 *>(o.lo + idx) = lv;
+    } else if (PX == 2) {
+      const bf16x2 hv = {h[0], h[1 % PX]}, lv = {l[0], l[1 % PX]};
+      *reinterpret_cast<bf16x2 *>(o.hi + idx) = hv;
+      if (o.lo) *reinterpret_cast<bf16x2 *>(o.lo + idx) = lv;
+    } else {
+      o.hi[idx] = h[0];
+      if (o.lo) o.lo[idx] = l[0];
+    }
+  }
+}
+
 template <int PX, int NCG>
 __global__ void __launch_bounds__(64 * NCG) corr_normalise_kernel(const float *__restrict__ x, const float *__restrict__ v,
-                                                             float *__restrict__ hat, float *__restrict__ nrm, int C, int F, int P) {
+                                                             HatOut hat, float *__restrict__ nrm, int C, int F, int P) {
   const int bf = blockIdx.y, b = bf / F, f = bf - b * F;
   const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int p0 = (blockIdx.x * 64 + lane) * PX;
@@ -90,7 +118,7 @@ __global__ void __launch_bounds__(64 * NCG) corr_normalise_kernel(const float *_
     den[e] = nn.v[e] + kNormEps;
   }
   if (!ok) return;
-  float *hp = hat + (int64_t)bf * C * P + p;
+  const int64_t hp = (int64_t)bf * C * P + p;
   for (int c0 = cg; c0 < C; c0 += NCG * NU) {
     PxV<PX> t[NU];
 #pragma unroll
@@ -100,7 +128,7 @@ __global__ void __launch_bounds__(64 * NCG) corr_normalise_kernel(const float *_
     for (int u = 0; u < NU; ++u) {
 #pragma unroll
       for (int e = 0; e < PX; ++e) t[u].v[e] = (t[u].v[e] * m.v[e]) / den[e];
-      if (c0 + NCG * u < C) stv<PX>(hp + (int64_t)(c0 + NCG * u) * P, t[u]);
+      if (c0 + NCG * u < C) st_hat<PX>(hat, hp + (int64_t)(c0 + NCG * u) * P, t[u]);
     }
   }
   if (cg == 0) stv<PX>(nrm + (int64_t)bf * P + p, nn);
@@ -110,7 +138,7 @@ __global__ void __launch_bounds__(64 * NCG) corr_normalise_kernel(const float *_
 // (the two-loop kernel fetched 1.5x the algorithmic bytes at C2: its second walk missed L2).  Same operation order.
 template <int PX, int NCG, int KU>
 __global__ void __launch_bounds__(64 * NCG) corr_normalise_keep_kernel(const float *__restrict__ x, const float *__restrict__ v,
-                                                                  float *__restrict__ hat, float *__restrict__ nrm, int C, int F, int P) {
+                                                                  HatOut hat, float *__restrict__ nrm, int C, int F, int P) {
   const int bf = blockIdx.y, b = bf / F, f = bf - b * F;
   const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int p0 = (blockIdx.x * 64 + lane) * PX;
@@ -155,12 +183,12 @@ __global__ void __launch_bounds__(64 * NCG) corr_normalise_keep_kernel(const flo
     den[e] = nn.v[e] + kNormEps;
   }
   if (!ok) return;
-  float *hp = hat + (int64_t)bf * C * P + p;
+  const int64_t hp = (int64_t)bf * C * P + p;
 #pragma unroll
   for (int u = 0; u < KU; ++u) {
 #pragma unroll
     for (int e = 0; e < PX; ++e) t[u].v[e] = t[u].v[e] / den[e];
-    if (cg + NCG * u < C) stv<PX>(hp + (int64_t)(cg + NCG * u) * P, t[u]);
+    if (cg + NCG * u < C) st_hat<PX>(hat, hp + (int64_t)(cg + NCG * u) * P, t[u]);
   }
   if (cg == 0) stv<PX>(nrm + (int64_t)bf * P + p, nn);
 }
@@ -568,6 +596,24 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
     for (int i = 0; i < TM; ++i) {
       float bv = -INFINITY;
       int bi = 0x7fffffff;
+      if (FULL) {
+        // whole tiles: three vector instructions per element (compare, two selects; the running index is the element's position
+        // in the lane's ascending column order, an inline constant) - this scan is most of a bf16 tile's epilogue, and vector
+        // instructions take matrix-pipe issue slots from the other waves of the SIMD
+        int li = 0;
+        bv = acc[i][0][0];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (j == 0 && r == 0) continue;
+            const float v = acc[i][j][r];
+            const bool gt = v > bv;
+            bv = gt ? v : bv;
+            li = gt ? j * 16 + r : li;
+          }
+        bi = n0 + wn0 + (li >> 4) * 32 + ((li >> 2) & 3) * 8 + 4 * lh + (li & 3);
+      } else
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -1221,8 +1267,6 @@ static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
 //   MC operand (row contiguous in global): [k][row], row stride = ROWS + 32 elements -> fragment = two
 //     ds_read_b64_tr_b16 (the hardware transposing read; conflict-free at this stride), so that neither the
 //     NCHW feature planes nor the cotangent volume ever need a transposed copy in HBM.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -1494,6 +1538,254 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
+// ---- forward contraction on ready-made bf16 operands (TCL_PREC_BF16 / BF16X3).  Both operands k-major ([c][pixel], the
+// NCHW order the normalisation writes them in); `hi` (and `lo`) images come from corr_normalise*: the k-loop holds no
+// conversion, only 16-byte loads -> 16-byte LDS writes -> transposing fragment reads -> MFMAs.  Two LDS stages for NS = 1
+// (ONE barrier per k-tile), one stage for NS = 2 (hi + lo images of both operands already fill 40 KB).  The epilogues are
+// gemm_epilogue's: whole-line non-temporal stores through LDS, or the fused row argmax (EPI_ARGMAX: the volume never exists).
+template <int ROWS, int NT, int BKT>
+struct TileLoaderB {
+  static constexpr int NV = ROWS * BKT / 8 / NT;   // 16-byte pieces (8 bf16) per thread
+  static_assert(ROWS * BKT / 8 % NT == 0 && NV >= 1, "tile must divide over the block");
+  u32x4 r[NV];
+  __device__ __forceinline__ static void thread_offsets(uint32_t (&off)[NV], int64_t ld, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      off[i] = ((uint32_t)(idx / (ROWS / 8)) * (uint32_t)ld + (uint32_t)(idx % (ROWS / 8)) * 8u) * 2u;
+    }
+  }
+  __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rsrc, const uint32_t (&off)[NV], int soff) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off[i], soff, 0);
+  }
+  // ragged shapes: element-wise, bounds-checked (rows >= `rows` and k >= `depth` read as zero)
+  __device__ __forceinline__ void load(const __bf16 *base, int64_t ld, int row0, int k0, int rows, int depth, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT, k = k0 + idx / (ROWS / 8), row = row0 + (idx % (ROWS / 8)) * 8;
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (k < depth && row + j < rows) ? reinterpret_cast<const unsigned short *>(base)[(int64_t)k * ld + row + j] : (unsigned short)0;
+      const u32x4 v = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
+                       (unsigned)e[6] | ((unsigned)e[7] << 16)};
+      r[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(__bf16 *img, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      *reinterpret_cast<u32x4 *>(img + (idx / (ROWS / 8)) * McLd<ROWS>::value + (idx % (ROWS / 8)) * 8) = r[i];
+    }
+  }
+};
+
+struct Bf16Ops { const __bf16 *a_hi, *a_lo, *b_hi, *b_lo; };
+
+// Pipeline (the wide fp32 kernel's, with two 16-deep MFMA groups per 32-deep k-tile): two LDS stages and ONE barrier per k-tile,
+// placed between the tile's two groups.  Before it a wave reads its group-1 fragments, writes its share of the NEXT tile to the
+// other stage, issues the loads of the tile after that, and multiplies group 0 (whose fragments it read one phase earlier);
+// after it, the first fragments of the next tile are read while group 1 is multiplied.  Every LDS read has a whole group of
+// MFMAs (4 or 12) to land under; the matrix pipe of a SIMD never waits on its own wave's LDS round trip.
+// D = k-tiles in flight in registers beyond the staged one (the loop is unrolled D times, ktiles % D == 0): with one tile a wave
+// had 4 x 16 bytes per lane on their way from L2 for ~0.3 us of MFMA work per k-tile, less than the loaded L2 latency.
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool FULL, int D>
+__global__ void __launch_bounds__(WM *WN * 64, (NS == 1 && (BM / WM) * (BN / WN) <= 64 * 64) ? 3 : 2) gemm_bf16op_kernel(GemmArgs g, Bf16Ops o) {
+  constexpr int NT = WM * WN * 64, BKT = 32;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_IMG = BKT * McLd<BM>::value, B_IMG = BKT * McLd<BN>::value, STAGE = NS * (A_IMG + B_IMG);
+  constexpr int SMEM_F = 2 * STAGE / 2;   // the buffer in floats (epilogue staging)
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_bf16op[];
+  __bf16 *smem = smem_bf16op;
+
+  const unsigned per_batch = g.tiles_m * g.tiles_n;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned z = lin / per_batch, local = lin - z * per_batch;
+  constexpr unsigned GROUP = 8;
+  const unsigned gw = GROUP * g.tiles_n;
+  const unsigned gid = local / gw, first_m = gid * GROUP;
+  const unsigned gsz = min((unsigned)g.tiles_m - first_m, GROUP);
+  const unsigned tm = first_m + (local % gw) % gsz, tn = (local % gw) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
+
+  const int64_t a_base = (int64_t)(z / g.a_bdiv) * g.a_bs, b_base = (int64_t)z * g.b_bs;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TileLoaderB<BM, NT, BKT> la[D][NS];
+  TileLoaderB<BN, NT, BKT> lb[D][NS];
+  const int ktiles = (g.K + BKT - 1) / BKT;
+  uint32_t a_off[la[0][0].NV], b_off[lb[0][0].NV];
+  __amdgpu_buffer_rsrc_t ra[NS], rb[NS];
+  if (FULL) {
+    la[0][0].thread_offsets(a_off, g.a_ld, tid);
+    lb[0][0].thread_offsets(b_off, g.b_ld, tid);
+    ra[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(o.a_hi + a_base + m0), 0, 0x7fffffff, 0x00020000);
+    rb[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(o.b_hi + b_base + n0), 0, 0x7fffffff, 0x00020000);
+    if (NS == 2) {
+      ra[NS - 1] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(o.a_lo + a_base + m0), 0, 0x7fffffff, 0x00020000);
+      rb[NS - 1] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(o.b_lo + b_base + n0), 0, 0x7fffffff, 0x00020000);
+    }
+  }
+  const int a_k = (int)(BKT * g.a_ld * 2), b_k = (int)(BKT * g.b_ld * 2);   // bytes from one k-tile to the next
+  auto fetch = [&](auto setc, int t) {   // k-tile t -> register set SET
+    constexpr int SET = decltype(setc)::value;
+    if (FULL) {
+#pragma unroll
+      for (int h = 0; h < NS; ++h) { la[SET][h].load_buf(ra[h], a_off, t * a_k); lb[SET][h].load_buf(rb[h], b_off, t * b_k); }
+    } else {
+      la[SET][0].load(o.a_hi + a_base, g.a_ld, m0, t * BKT, g.M, g.K, tid);
+      lb[SET][0].load(o.b_hi + b_base, g.b_ld, n0, t * BKT, g.N, g.K, tid);
+      if (NS == 2) {
+        la[SET][NS - 1].load(o.a_lo + a_base, g.a_ld, m0, t * BKT, g.M, g.K, tid);
+        lb[SET][NS - 1].load(o.b_lo + b_base, g.b_ld, n0, t * BKT, g.N, g.K, tid);
+      }
+    }
+  };
+  auto stage = [&](auto setc, int st) {   // register set SET -> LDS stage st: [A hi][A lo][B hi][B lo]
+    constexpr int SET = decltype(setc)::value;
+    __bf16 *base = smem + st * STAGE;
+#pragma unroll
+    for (int h = 0; h < NS; ++h) { la[SET][h].store(base + h * A_IMG, tid); lb[SET][h].store(base + NS * A_IMG + h * B_IMG, tid); }
+  };
+  struct Frags { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto read_frags = [&](Frags &f, int st, int ks) {
+    const __bf16 *Ah = smem + st * STAGE, *Al = Ah + (NS - 1) * A_IMG, *Bh = Ah + NS * A_IMG, *Bl = Bh + (NS - 1) * B_IMG;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      f.ah[i] = read_frag_h<BM, false>(Ah, wm0 + i * 32, ks, lane);
+      if (NS == 2) f.al[i] = read_frag_h<BM, false>(Al, wm0 + i * 32, ks, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f.bh[j] = read_frag_h<BN, false>(Bh, wn0 + j * 32, ks, lane);
+      if (NS == 2) f.bl[j] = read_frag_h<BN, false>(Bl, wn0 + j * 32, ks, lane);
+    }
+  };
+  auto mma = [&](const Frags &f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (NS == 2) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);   // transposed tiles, see gemm_epilogue
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+      }
+  };
+  Frags f0, f1;
+  using S0 = std::integral_constant<int, 0>;
+  fetch(S0{}, 0);
+  stage(S0{}, 0);
+  {   // tiles 1 .. D on their way: tile j in set j % D
+    auto pre = [&](auto jc) { constexpr int J = decltype(jc)::value; if (J <= D) fetch(std::integral_constant<int, J % D>{}, min(J, ktiles - 1)); };
+    pre(std::integral_constant<int, 1>{}); pre(std::integral_constant<int, 2>{}); pre(std::integral_constant<int, 3>{}); pre(std::integral_constant<int, 4>{});
+    static_assert(D <= 4, "prologue covers D <= 4");
+  }
+  __syncthreads();
+  read_frags(f0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  // The body is straight-line (no branch: hipcc's waits then COUNT the outstanding LDS / memory operations instead of draining
+  // them at a join).  Past the last tile the staging simply runs on: the loads re-read the last tile, the other stage receives
+  // a copy nobody multiplies.
+  auto ktile = [&](auto uc, int t) {   // k-tile t + U of an unrolled trip (t % D == 0)
+    constexpr int U = decltype(uc)::value;
+    if (U >= D) return;
+    const int st = D % 2 == 0 ? (U & 1) : ((t + U) & 1);
+    using NEXT = std::integral_constant<int, (U + 1) % D>;   // the set that holds tile t + U + 1
+    read_frags(f1, st, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f0);                             // queued BEFORE the wave may have to wait for the next tile's global loads
+    __builtin_amdgcn_sched_barrier(0);
+    stage(NEXT{}, 1 - st);               // everyone left that stage before the barrier of the previous k-tile
+    fetch(NEXT{}, min(t + U + 1 + D, ktiles - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                     // all waves: group-1 fragments of this tile in registers, the next tile staged
+    read_frags(f0, 1 - st, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#pragma unroll 1
+  for (int t = 0; t < ktiles; t += D) {
+    ktile(std::integral_constant<int, 0>{}, t); ktile(std::integral_constant<int, 1>{}, t);
+    ktile(std::integral_constant<int, 2>{}, t); ktile(std::integral_constant<int, 3>{}, t);
+  }
+  __syncthreads();
+  gemm_epilogue<BM, BN, WM, WN, EPI, FULL, SMEM_F>(acc, reinterpret_cast<float *>(smem), g, z, m0, n0, tn);
+}
+
+// Measured at C2 (round 3): 128 x 128 tiles with two k-tiles in flight.  256 x 128 tiles (4 waves of 128 x 64, or 8 of 64 x 64):
+// store variant 0.258 / 0.287 ms against 0.224, fused argmax 0.228 / 0.241 against 0.225; one or four k-tiles in flight:
+// 0.215 / 0.246 ms against 0.222.  The matrix pipe is busy 0.40 of the kernel's cycles in all of them (SQ_VALU_MFMA_BUSY_CYCLES,
+// 2.1 GHz under this load): at K = 256 a tile's 64 MFMAs per wave stand against ~420 vector instructions per wave (zero fill,
+// addresses, the argmax scan / the LDS-transposed store), which take issue slots from the SIMD's other waves.
+constexpr int BF16_D = 2;
+#define TCL_BF16_TILE 128, 128, 2, 2
+// dynamic LDS above 64 KB needs the kernel attribute raised once per device (cached under a mutex, like wide_kernel_ready)
+template <typename K>
+static bool bf16op_lds_ready(K kernel, size_t lds) {
+  if (lds <= 64 * 1024) return true;
+  static std::mutex mu;
+  static signed char ok[64];   // 0 = not asked yet, 1 = granted, -1 = refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (ok[dev] == 0) {
+    const bool granted = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (!granted) (void)hipGetLastError();
+    ok[dev] = granted ? 1 : -1;
+  }
+  return ok[dev] > 0;
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+static int launch_gemm_bf16op(GemmArgs g, const Bf16Ops &o, int nsplit, hipStream_t s, const char *what) {
+  g.tiles_m = (int)cdiv(g.M, BM);
+  g.tiles_n = (int)cdiv(g.N, BN);
+  g.d_vec = aligned(g.D, 16) && g.d_ld % 4 == 0 && g.d_bs % 4 == 0;
+  const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
+  TCL_REQUIRE(blocks > 0 && blocks < (1LL << 31), TCL_ERR_SHAPE, "%s: grid of %ld blocks", what, (long)blocks);
+  // full tiles, 16-byte aligned operand rows, and the byte offsets of one block's operand panels (K x ld) inside 31 bits
+  const bool full = g.M % BM == 0 && g.N % BN == 0 && g.K % 32 == 0 && g.a_ld % 8 == 0 && g.b_ld % 8 == 0 && g.a_bs % 8 == 0 && g.b_bs % 8 == 0 &&
+                    aligned(o.a_hi, 16) && aligned(o.b_hi, 16) && aligned(o.a_lo, 16) && aligned(o.b_lo, 16) &&
+                    (int64_t)g.K * g.a_ld * 2 < (1LL << 31) && (int64_t)g.K * g.b_ld * 2 < (1LL << 31) &&
+                    (EPI != EPI_STORE || (g.d_vec && (int64_t)BM * g.d_ld * 4 < (1LL << 31)));
+  const dim3 grd((unsigned)blocks), blk(WM * WN * 64);
+  const size_t lds = (size_t)2 * nsplit * 32 * (McLd<BM>::value + McLd<BN>::value) * sizeof(__bf16);
+  const int ktiles = (int)cdiv(g.K, 32);
+#define TCL_LAUNCH_BF16OP_D(NS, FULLV, DV)                                                                                \
+  do {                                                                                                                     \
+    auto kern = gemm_bf16op_kernel<BM, BN, WM, WN, NS, EPI, FULLV, DV>;                                                    \
+    TCL_REQUIRE(bf16op_lds_ready(kern, lds), TCL_ERR_LAUNCH, "%s: the device refused %zu bytes of dynamic LDS", what, lds); \
+    hipLaunchKernelGGL(kern, grd, blk, lds, s, g, o);                                                                      \
+  } while (0)
+#define TCL_LAUNCH_BF16OP(NS, FULLV)                                            \
+  do {                                                                           \
+    if (FULLV && ktiles % BF16_D == 0) TCL_LAUNCH_BF16OP_D(NS, FULLV, BF16_D); \
+    else TCL_LAUNCH_BF16OP_D(NS, FULLV, 1);                                     \
+  } while (0)
+  if (nsplit == 2) {
+    if (full) TCL_LAUNCH_BF16OP(2, true);
+    else TCL_LAUNCH_BF16OP(2, false);
+  } else {
+    if (full) TCL_LAUNCH_BF16OP(1, true);
+    else TCL_LAUNCH_BF16OP(1, false);
+  }
+#undef TCL_LAUNCH_BF16OP_D
+#undef TCL_LAUNCH_BF16OP
+  return check_launch(what);
+}
+
 static bool gemm_vec_ok(const GemmArgs &g, bool a_kc, bool b_kc) {
   return aligned(g.A, 16) && aligned(g.B, 16) && g.a_ld % 4 == 0 && g.b_ld % 4 == 0 && g.a_bs % 4 == 0 && g.b_bs % 4 == 0 &&
          g.a_ss % 4 == 0 && g.b_ss % 4 == 0 && (a_kc ? g.K % 4 == 0 : g.M % 4 == 0) && (b_kc ? g.K % 4 == 0 : g.N % 4 == 0);
@@ -1529,17 +1821,30 @@ static int launch_gemm_bf16(GemmArgs g, int nsplit, hipStream_t s, const char *w
 
 // ------------------------------------------------------------------------------------------ workspace layout
 struct CorrWs {
-  float *a_hat, *r_hat, *n_t, *n_r;
+  float *a_hat, *r_hat, *n_t, *n_r;      // fp32 operands (NULL when not kept) and the norms
+  __bf16 *a_hi, *r_hi, *a_lo, *r_lo;     // bf16 operand images (TCL_PREC_BF16: hi; TCL_PREC_BF16X3: hi + lo), same element order
   size_t bytes;
 };
-static CorrWs corr_ws(void *base, int64_t B, int64_t C, int64_t F, int64_t P) {
-  CorrWs w;
+// Layout: [a^ r^ fp32 (keep_f32)] [norms] [a^ r^ hi (bf16 variants)] [a^ r^ lo (bf16x3)].  The fp32 images come first, so the
+// backward pass (which multiplies the fp32 operands in every variant) finds them where the fp32 forward leaves them.
+static CorrWs corr_ws(void *base, int64_t B, int64_t C, int64_t F, int64_t P, int precision, bool keep_f32 = true) {
+  CorrWs w{};
   size_t off = 0;
-  auto take = [&](size_t n) { float *p = (float *)((char *)base + off); off += round_up(n * sizeof(float), 256); return p; };
-  w.a_hat = take((size_t)B * C * P);
-  w.r_hat = take((size_t)B * F * C * P);
-  w.n_t = take((size_t)B * P);
-  w.n_r = take((size_t)B * F * P);
+  auto take = [&](size_t nbytes) { void *p = (char *)base + off; off += round_up(nbytes, 256); return p; };
+  if (keep_f32) {
+    w.a_hat = (float *)take((size_t)B * C * P * 4);
+    w.r_hat = (float *)take((size_t)B * F * C * P * 4);
+  }
+  w.n_t = (float *)take((size_t)B * P * 4);
+  w.n_r = (float *)take((size_t)B * F * P * 4);
+  if (precision != TCL_PREC_F32) {
+    w.a_hi = (__bf16 *)take((size_t)B * C * P * 2);
+    w.r_hi = (__bf16 *)take((size_t)B * F * C * P * 2);
+    if (precision == TCL_PREC_BF16X3) {
+      w.a_lo = (__bf16 *)take((size_t)B * C * P * 2);
+      w.r_lo = (__bf16 *)take((size_t)B * F * C * P * 2);
+    }
+  }
   w.bytes = off;
   return w;
 }
@@ -1662,9 +1967,8 @@ using namespace tcl;
 
 // ============================================================================================ C ABI
 extern "C" size_t tcl_corr4d_fwd_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P, int precision) {
-  (void)precision;
   if (B <= 0 || C <= 0 || F <= 0 || P <= 0) return 0;
-  return corr_ws(nullptr, B, C, F, P).bytes;
+  return corr_ws(nullptr, B, C, F, P, precision).bytes;
 }
 
 
@@ -1672,13 +1976,13 @@ extern "C" size_t tcl_corr4d_fwd_workspace_bytes(int64_t B, int64_t C, int64_t F
 static bool norm_vec_ok(int64_t P, const void *a, const void *b, const void *c, const void *d, const void *e) {
   return P % 4 == 0 && aligned(a, 16) && aligned(b, 16) && aligned(c, 16) && aligned(d, 16) && aligned(e, 16);
 }
-static void launch_normalise(hipStream_t s, const float *x, const float *v, float *hat, float *nrm, int64_t BF, int C, int F, int64_t P) {
+static void launch_normalise(hipStream_t s, const float *x, const float *v, HatOut hat, float *nrm, int64_t BF, int C, int F, int64_t P) {
 #ifdef TCL_NORM_NO_KEEP   // A/B switch of side builds (-DTCL_NORM_NO_KEEP): the two-loop kernels everywhere
   const bool keep = false;
 #else
   const bool keep = true;
 #endif
-  const bool vec = norm_vec_ok(P, x, v, hat, nrm, nullptr);
+  const bool vec = norm_vec_ok(P, x, v, hat.f, nrm, nullptr) && aligned(hat.hi, 16) && aligned(hat.lo, 16);
 #define TCL_NORM_KEEP(NCG) hipLaunchKernelGGL((corr_normalise_keep_kernel<2, NCG, 16>), dim3((unsigned)cdiv(P, 128), (unsigned)BF), dim3(64 * NCG), 0, s, x, v, hat, nrm, C, F, (int)P)
   if (vec && keep && C <= 256) {   // single read of x: the thread's <= 16 channels stay in registers
     if (C <= 64) TCL_NORM_KEEP(4);
@@ -1734,12 +2038,23 @@ extern "C" int tcl_corr4d_fwd(const float *x_t, const float *v_t, const float *x
   TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
               "tcl_corr4d_fwd: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
   hipStream_t s = (hipStream_t)stream;
-  const CorrWs w = corr_ws(workspace, B, C, F, P);
-  launch_normalise(s, x_t, v_t, w.a_hat, w.n_t, B, (int)C, 1, P);
-  launch_normalise(s, x_r, v_r, w.r_hat, w.n_r, B * F, (int)C, (int)F, P);
+  const CorrWs w = corr_ws(workspace, B, C, F, P, precision);
+  launch_normalise(s, x_t, v_t, HatOut{w.a_hat, w.a_hi, w.a_lo}, w.n_t, B, (int)C, 1, P);
+  launch_normalise(s, x_r, v_r, HatOut{w.r_hat, w.r_hi, w.r_lo}, w.n_r, B * F, (int)C, (int)F, P);
   rc = check_launch("tcl_corr4d_fwd(normalise)");
   if (rc) return rc;
   return tcl_corr4d_contract(workspace, out, B, C, F, P, precision, stream);
+}
+
+// the contraction's operand description: out[p][q] = sum_c a^[c][p] r^[c][q], one GEMM per (b, f)
+static GemmArgs corr_fwd_gemm(const CorrWs &w, float *out, int64_t B, int64_t C, int64_t F, int64_t P) {
+  GemmArgs g{};
+  g.A = w.a_hat; g.B = w.r_hat; g.D = out;
+  g.M = (int)P; g.N = (int)P; g.K = (int)C; g.nseg = 1;
+  g.a_ld = P; g.b_ld = P; g.d_ld = P;
+  g.a_bs = C * P; g.b_bs = C * P; g.d_bs = P * P;
+  g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
+  return g;
 }
 
 extern "C" int tcl_corr4d_contract(const void *fwd_workspace, float *out, int64_t B, int64_t C, int64_t F, int64_t P, int precision,
@@ -1747,56 +2062,45 @@ extern "C" int tcl_corr4d_contract(const void *fwd_workspace, float *out, int64_
   int rc = corr_check("tcl_corr4d_contract", B, C, F, P, precision);
   if (rc) return rc;
   TCL_REQUIRE(fwd_workspace && aligned(fwd_workspace, 256) && out, TCL_ERR_ARG, "tcl_corr4d_contract: NULL / misaligned pointer");
-  const CorrWs w = corr_ws(const_cast<void *>(fwd_workspace), B, C, F, P);
-  GemmArgs g{};
-  g.A = w.a_hat; g.B = w.r_hat; g.D = out;
-  g.M = (int)P; g.N = (int)P; g.K = (int)C; g.nseg = 1;
-  g.a_ld = P; g.b_ld = P; g.d_ld = P;
-  g.a_bs = C * P; g.b_bs = C * P; g.d_bs = P * P;
-  g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
-  if (precision != TCL_PREC_F32)
-    return launch_gemm_bf16<128, 128, 2, 2, false, false>(g, precision == TCL_PREC_BF16X3 ? 2 : 1, (hipStream_t)stream, "tcl_corr4d_contract(bf16 gemm)");
-#ifndef TCL_FWD_TILE   // A/B switch: block tile of the forward contraction (BM, BN, WM, WN)
-#define TCL_FWD_TILE 128, 128, 2, 2
-#endif
-#ifdef TCL_GEMM_WIDE_FWD
-  if (gemm_wide_ok(g, false, false))
-    if (const int cus = wide_kernel_ready<false, false, true>()) return launch_gemm_wide<false, false, true>(g, cus, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
-#endif
-  return launch_gemm<TCL_FWD_TILE, false, false>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
+  const CorrWs w = corr_ws(const_cast<void *>(fwd_workspace), B, C, F, P, precision);
+  const GemmArgs g = corr_fwd_gemm(w, out, B, C, F, P);
+  if (precision != TCL_PREC_F32)   // the bf16 images the normalisation left behind the fp32 ones
+    return launch_gemm_bf16op<TCL_BF16_TILE, EPI_STORE>(g, Bf16Ops{w.a_hi, w.a_lo, w.r_hi, w.r_lo}, precision == TCL_PREC_BF16X3 ? 2 : 1,
+                                                         (hipStream_t)stream, "tcl_corr4d_contract(bf16 gemm)");
+  return launch_gemm<128, 128, 2, 2, false, false>(g, (hipStream_t)stream, "tcl_corr4d_contract(gemm)");
 }
 
 constexpr int ARGMAX_BN = 128;
-extern "C" size_t tcl_corr4d_argmax_flow_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P) {
+extern "C" size_t tcl_corr4d_argmax_flow_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P, int precision) {
   if (B <= 0 || C <= 0 || F <= 0 || P <= 0) return 0;
-  return corr_ws(nullptr, B, C, F, P).bytes + round_up((size_t)B * F * P * cdiv(P, ARGMAX_BN) * sizeof(float2), 256);
+  return corr_ws(nullptr, B, C, F, P, precision, precision == TCL_PREC_F32).bytes + round_up((size_t)B * F * P * cdiv(P, ARGMAX_BN) * sizeof(float2), 256);
 }
 
 extern "C" int tcl_corr4d_argmax_flow(const float *x_t, const float *v_t, const float *x_r, const float *v_r, float *flow, int64_t B,
-                                      int64_t C, int64_t F, int64_t S, void *workspace, size_t workspace_bytes, void *stream) {
+                                      int64_t C, int64_t F, int64_t S, int precision, void *workspace, size_t workspace_bytes, void *stream) {
   const int64_t P = S * S;
-  int rc = corr_check("tcl_corr4d_argmax_flow", B, C, F, P, TCL_PREC_F32);
+  int rc = corr_check("tcl_corr4d_argmax_flow", B, C, F, P, precision);
   if (rc) return rc;
   TCL_REQUIRE(S > 1, TCL_ERR_SHAPE, "tcl_corr4d_argmax_flow: S must be > 1");
   TCL_REQUIRE(x_t && x_r && flow && aligned(flow, 8), TCL_ERR_ARG, "tcl_corr4d_argmax_flow: NULL / misaligned pointer");
-  const size_t need = tcl_corr4d_argmax_flow_workspace_bytes(B, C, F, P);
+  const size_t need = tcl_corr4d_argmax_flow_workspace_bytes(B, C, F, P, precision);
   TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
               "tcl_corr4d_argmax_flow: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
   hipStream_t s = (hipStream_t)stream;
-  const CorrWs w = corr_ws(workspace, B, C, F, P);
+  // inference only (no backward pass follows): the bf16 variants write just the bf16 operand images
+  const CorrWs w = corr_ws(workspace, B, C, F, P, precision, precision == TCL_PREC_F32);
   float2 *part = (float2 *)((char *)workspace + w.bytes);
   const dim3 blk(256);
-  launch_normalise(s, x_t, v_t, w.a_hat, w.n_t, B, (int)C, 1, P);
-  launch_normalise(s, x_r, v_r, w.r_hat, w.n_r, B * F, (int)C, (int)F, P);
+  launch_normalise(s, x_t, v_t, HatOut{w.a_hat, w.a_hi, w.a_lo}, w.n_t, B, (int)C, 1, P);
+  launch_normalise(s, x_r, v_r, HatOut{w.r_hat, w.r_hi, w.r_lo}, w.n_r, B * F, (int)C, (int)F, P);
   rc = check_launch("tcl_corr4d_argmax_flow(normalise)");
   if (rc) return rc;
-  GemmArgs g{};
-  g.A = w.a_hat; g.B = w.r_hat; g.D = (float *)part;
-  g.M = (int)P; g.N = (int)P; g.K = (int)C; g.nseg = 1;
-  g.a_ld = P; g.b_ld = P; g.d_ld = P;
-  g.a_bs = C * P; g.b_bs = C * P; g.d_bs = 0;
-  g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
-  rc = launch_gemm<128, ARGMAX_BN, 2, 2, false, false, EPI_ARGMAX>(g, s, "tcl_corr4d_argmax_flow(gemm)");
+  GemmArgs g = corr_fwd_gemm(w, (float *)part, B, C, F, P);
+  g.d_bs = 0;
+  if (precision != TCL_PREC_F32)
+    rc = launch_gemm_bf16op<TCL_BF16_TILE, EPI_ARGMAX>(g, Bf16Ops{w.a_hi, w.a_lo, w.r_hi, w.r_lo}, precision == TCL_PREC_BF16X3 ? 2 : 1, s,
+                                                              "tcl_corr4d_argmax_flow(bf16 gemm)");
+  else rc = launch_gemm<128, ARGMAX_BN, 2, 2, false, false, EPI_ARGMAX>(g, s, "tcl_corr4d_argmax_flow(gemm)");
   if (rc) return rc;
   const int64_t rows = B * F * P;
   int64_t blocks = cdiv(rows, 256);
@@ -1823,7 +2127,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
   TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
               "tcl_corr4d_bwd: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
   hipStream_t s = (hipStream_t)stream;
-  const CorrWs w = corr_ws(const_cast<void *>(fwd_workspace), B, C, F, P);
+  const CorrWs w = corr_ws(const_cast<void *>(fwd_workspace), B, C, F, P, precision);
   float *d_a = (float *)workspace;
   float *d_r = (float *)((char *)workspace + round_up((size_t)B * C * P * 4, 256));
   const int nsplit = precision == TCL_PREC_BF16X3 ? 2 : 1;

@@ -98,6 +98,21 @@ class Experiment:
         return sorted(int(f.split(".")[0]) for f in os.listdir(self.paths["checkpoints"]) if f.endswith(".checkpoint.pkl"))
 
 
+def _plain(obj):
+    """numpy scalars / arrays (the reference's loss histories hold np.mean results) -> Python numbers / tensors, recursively, so that
+    a checkpoint stays readable by torch.load(weights_only=True)."""
+    import numpy as np
+    if isinstance(obj, dict):
+        return {k: _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_plain(v) for v in obj)
+    if isinstance(obj, np.generic):
+        return obj.item()
+    if isinstance(obj, np.ndarray):
+        return torch.from_numpy(obj)
+    return obj
+
+
 class Runner:
     """The hook protocol of skeltorch.Runner as the reference's ThesisRunner uses it."""
 
@@ -153,7 +168,7 @@ class Runner:
         data = {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "counters": dict(self.counters),
                 "losses_epoch": self.losses_epoch}
         data.update(self.save_states_others())
-        torch.save(data, self.experiment.checkpoint_path(self.counters["epoch"]))
+        torch.save(_plain(data), self.experiment.checkpoint_path(self.counters["epoch"]))
 
     def load_states(self, epoch, device):
         # everything save_states writes is tensors + plain containers (state_dicts, counters, float dicts): the weights-only loader

@@ -44,7 +44,7 @@ def test_ctypes_table_matches_header():
 def test_version_and_validation_without_gpu():
     from master_thesis_amd import _lib
     lib = _lib.lib()
-    assert lib.tcl_version() == 100
+    assert lib.tcl_version() == 110
     # shape / argument errors are detected on the host before anything is launched
     assert lib.tcl_corr4d_fwd(None, None, None, None, None, 0, 1, 1, 1, 0, None, 0, None) == 1
     assert b"bad shape" in lib.tcl_last_error()
