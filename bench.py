@@ -147,7 +147,7 @@ def time_rotating(launchers, stream, rounds=6, warm=1):
     return e0.elapsed_time(e1) / (rounds * len(launchers))
 
 
-def measure_legs(dev, corr, warp_sets, c4_sets, groups=("corr", "warp", "c4")):
+def measure_legs(dev, corr, warp_sets, c4_sets, groups=("corr", "warp", "c4", "infer")):
     """Every dominant kernel / entry point of the step alone, cache-cold, against its roofline (SURVEY 8d byte counts)."""
     from master_thesis_amd import _lib
     lib = _lib.lib()
@@ -175,6 +175,8 @@ def measure_legs(dev, corr, warp_sets, c4_sets, groups=("corr", "warp", "c4")):
         _legs_warp(dev, warp_sets, add, stream, sp)
     if "c4" in groups:
         _legs_c4(dev, c4_sets, add, lib, stream, sp)
+    if "infer" in groups:
+        _legs_infer(dev, legs, stream)
     return legs
 
 
@@ -320,6 +322,73 @@ def _legs_c4(dev, c4_sets, add, lib, stream, sp):
         nbytes=B * (2 * C * (R + 1) * hw * 4 + (2 * C + 1) * hw * 4), note="read c_feats + grad p_in, write grad c_feats")
     add("ref_importance_c4", "ref_importance_kernel<4>", time_rotating([imp(q) for q in sets], stream), nbytes=B * 3 * (R + 1) * H * W * 4 + B * H * W * 4,
         note="write-only visualisation output (A9)")
+
+
+def _legs_infer(dev, legs, stream):
+    """The unit the reference's sequence schedulers issue thousands of times per sequence (thesis_dfpn/runner.py:153-159 after
+    the network): B = 1, one reference, 240 x 480.  Wall time per call (launch-bound: host work) against the GPU time of the same
+    kernels replayed from a captured graph, for the unfused formulation (1 - m, align_set, 1 - m, v_map: the reference's op list
+    on this package's kernels) and the fused single launch."""
+    from master_thesis_amd import _ops
+    from master_thesis_amd.utils import flow as flow_ops
+    g = torch.Generator(device="cpu").manual_seed(99)
+    H, W = 240, 480
+    x_ref = torch.rand(1, 3, 1, H, W, generator=g).to(dev)
+    m_ref = (torch.rand(1, 1, 1, H // 8, W // 8, generator=g) < 0.15).float().repeat_interleave(8, -2).repeat_interleave(8, -1).to(dev)
+    m_tgt = (torch.rand(1, 1, H // 8, W // 8, generator=g) < 0.15).float().repeat_interleave(8, -2).repeat_interleave(8, -1).to(dev)
+    lin_y, lin_x = torch.linspace(-1, 1, H), torch.linspace(-1, 1, W)
+    ys, xs = torch.meshgrid(lin_y, lin_x, indexing="ij")
+    fl = (torch.stack([xs, ys], -1)[None, None] * 1.03 + 0.02).to(dev).contiguous()
+
+    def unfused():
+        xa, va = flow_ops.align_set(x_ref, 1 - m_ref, fl)
+        return xa, va, _ops.vmap(va, 1 - m_tgt)
+
+    def fused():
+        return _ops.align_infer(x_ref, m_ref, fl, m_tgt)
+
+    def wall(fn, n=400):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    def replay(fn, n=200):
+        try:
+            side = torch.cuda.Stream(dev)
+            with torch.cuda.stream(side):
+                fn()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=side):
+                    for _ in range(10):
+                        fn()
+                gr.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                for _ in range(n // 10):
+                    gr.replay()
+                e1.record(side)
+                e1.synchronize()
+            return e0.elapsed_time(e1) / n * 1e3
+        except Exception as e:   # graph capture unavailable: report the wall time only
+            return None
+    with torch.no_grad():
+        a, b = unfused(), fused()
+        same = all(torch.equal(p, q) for p, q in zip(a, b))
+        w_u, w_f = wall(unfused), wall(fused)
+        k_u, k_f = replay(unfused), replay(fused)
+    rnd = lambda v: None if v is None else round(v, 2)
+    legs["infer_step_propagate"] = {
+        "shape": "B=1, 1 reference, 240x480 (thesis_dfpn/runner.py:153-159 after the network)", "bit_identical": bool(same),
+        "unfused": {"launches": 4, "wall_us_per_call": rnd(w_u), "gpu_us_per_call_graph_replay": rnd(k_u),
+                    "host_overhead_us": rnd(w_u - k_u) if k_u is not None else None},
+        "fused": {"launches": 1, "wall_us_per_call": rnd(w_f), "gpu_us_per_call_graph_replay": rnd(k_f),
+                  "host_overhead_us": rnd(w_f - k_f) if k_f is not None else None},
+        "wall_reduction": round(1 - w_f / w_u, 3)}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (numpy oracle)
@@ -481,6 +550,9 @@ def main():
         legs = measure_legs(dev, make_corr(dev, g) if "corr" in groups else None, [make_warp_set(dev, g) for _ in range(N_WARP)] if "warp" in groups else None,
                             [make_c4_set(dev, g) for _ in range(N_C4)] if "c4" in groups else None, groups)
         for k, v in legs.items():
+            if "ms_per_launch" not in v:
+                print(k, json.dumps(v), flush=True)
+                continue
             print("%-28s %8.4f ms  %8.1f %s  frac %.3f" % (k, v["ms_per_launch"], v["achieved"], v["unit"], v["frac"]), flush=True)
         return
     corr = make_corr(dev, g)

@@ -136,6 +136,24 @@ int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t x_sc,
                  int64_t NB, int64_t NF, int64_t C, int64_t H, int64_t W,
                  int align_corners, int v_mode, void *stream);
 
+/*   tcl_warp_fwd with the elementwise kernels around it folded in (the one-pair inference unit of the sequence schedulers,
+ *   thesis_dfpn/runner.py:153-159, and CPNet.align, models/cpn.py:283-290, issue them per call):
+ *     v_is_hole_mask != 0 : `v` holds HOLE masks m; the sampled visibility is 1 - m, flipped per tap in the kernel (the
+ *                           `1 - m` of models/cpn.py:288, thesis_dfpn/runner.py:157 never becomes a tensor);
+ *     v_target (nullable) : (NB,H,W) at v_target + b*vt_sb [hole mask when vt_is_hole_mask]; then v_map (strided like v_out)
+ *                           = clamp(v_out - v_target, 0, 1): T1 (thesis_dfpn/runner.py:158, models/cpn_original.py:287) in the
+ *                           warp's epilogue.  Needs v_mode != NONE, 3-channel frames, W >= 2.
+ *   All other arguments and every result as tcl_warp_fwd (which is this call with the extras off). */
+int tcl_warp_fwd_fused(const float *x, int64_t x_sb, int64_t x_sf, int64_t x_sc,
+                       const float *v, int64_t v_sb, int64_t v_sf, int v_is_hole_mask,
+                       const float *grid, const float *theta,
+                       float *x_out, int64_t xo_sb, int64_t xo_sf, int64_t xo_sc,
+                       float *v_out, int64_t vo_sb, int64_t vo_sf,
+                       const float *v_target, int64_t vt_sb, int vt_is_hole_mask,
+                       float *v_map, int64_t vm_sb, int64_t vm_sf,
+                       int64_t NB, int64_t NF, int64_t C, int64_t H, int64_t W,
+                       int align_corners, int v_mode, void *stream);
+
 /*   Backward of the bilinear branch: grad_x_out (strided like x_out) ->
  *     g_grid (NB*NF,H,W,2) or g_theta (NB*NF,2,3)  [whichever matches the forward; nullable]
  *     g_x    (strided like x; nullable; accumulated with float atomics into a buffer the CALLER zeroed).

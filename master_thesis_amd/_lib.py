@@ -31,6 +31,8 @@ SIGNATURES = {
     "tcl_corr1x1_bwd": (_INT, [_P] * 7 + [_I64] * 3 + [_P]),
     "tcl_warp_fwd": (_INT, [_P, _I64, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _P, _I64, _I64]
                      + [_I64] * 5 + [_INT, _INT, _P]),
+    "tcl_warp_fwd_fused": (_INT, [_P, _I64, _I64, _I64, _P, _I64, _I64, _INT, _P, _P, _P, _I64, _I64, _I64, _P, _I64, _I64,
+                                 _P, _I64, _INT, _P, _I64, _I64] + [_I64] * 5 + [_INT, _INT, _P]),
     "tcl_warp_bwd_workspace_bytes": (_SZ, [_I64] * 4 + [_INT]),
     "tcl_warp_bwd": (_INT, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _P, _P]
                      + [_I64] * 5 + [_INT, _P, _SZ, _P]),

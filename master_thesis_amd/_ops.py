@@ -43,8 +43,24 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def _workspace(nbytes, dev):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+_WS_CACHE = {}   # (device, stream, bytes) -> buffer, for calls no backward pass will follow
+
+
+def _workspace(nbytes, dev, cache=False):
+    """Scratch for one entry-point call.  With `cache` (the caller runs under no_grad: nothing will read the buffer after the
+    call's own kernels) the buffer of the last call of that size on this device and stream is handed out again: work on one
+    stream is ordered, so two calls never use it at once, and the one-pair inference loops of the sequence schedulers
+    (thousands of identical calls) stop going through the allocator."""
+    n = max(int(nbytes), 256)
+    if not cache:
+        return torch.empty(n, dtype=torch.uint8, device=dev)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, n)
+    buf = _WS_CACHE.get(key)
+    if buf is None:
+        if len(_WS_CACHE) >= 32:
+            _WS_CACHE.clear()
+        buf = _WS_CACHE[key] = torch.empty(n, dtype=torch.uint8, device=dev)
+    return buf
 
 
 def _planes(t, h, w):
@@ -69,7 +85,7 @@ class Corr4dFn(torch.autograd.Function):
         vr = None if v_r is None else v_r.expand(b, 1, f, h, w).contiguous()
         out = torch.empty((b, f, h, w, h, w), dtype=torch.float32, device=dev)
         lib = _lib.lib()
-        ws = _workspace(lib.tcl_corr4d_fwd_workspace_bytes(b, c, f, p, precision), dev)
+        ws = _workspace(lib.tcl_corr4d_fwd_workspace_bytes(b, c, f, p, precision), dev, cache=not any(ctx.needs_input_grad))
         with torch.cuda.device(dev):
             _lib.call("tcl_corr4d_fwd", _p(xt), _p(vt), _p(xr), _p(vr), _p(out), b, c, f, p, precision,
                       _p(ws), ws.numel(), _stream(dev))
@@ -128,7 +144,7 @@ def corr4d_argmax_flow(x_t, v_t, x_r, v_r, precision=None):
     vt = None if v_t is None else v_t.expand(b, 1, h, w).contiguous()
     vr = None if v_r is None else v_r.expand(b, 1, f, h, w).contiguous()
     flow = torch.empty((b, f, h, w, 2), dtype=torch.float32, device=dev)
-    ws = _workspace(_lib.lib().tcl_corr4d_argmax_flow_workspace_bytes(b, c, f, p, prec), dev)
+    ws = _workspace(_lib.lib().tcl_corr4d_argmax_flow_workspace_bytes(b, c, f, p, prec), dev, cache=True)
     with torch.cuda.device(dev):
         _lib.call("tcl_corr4d_argmax_flow", _p(xt), _p(vt), _p(xr), _p(vr), _p(flow), b, c, f, h, prec, _p(ws), ws.numel(), _stream(dev))
     return flow
@@ -193,7 +209,9 @@ class WarpFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, v, grid, theta, align_corners, v_mode, frames=None):
+    def forward(ctx, x, v, grid, theta, align_corners, v_mode, frames=None, v_is_hole=False):
+        """`v_is_hole`: v holds the reference's HOLE masks m; the kernel samples 1 - m (flipped per tap), so the `1 - m`
+        tensor of models/cpn.py:288 / thesis_dfpn/runner.py:157 is never made."""
         dev = _require_device(x, v, grid, theta)
         b, c, f_src, h, w = x.shape
         runs = [(0, 0, f_src)] if frames is None else _frame_runs([int(i) for i in frames], f_src)
@@ -218,12 +236,13 @@ class WarpFn(torch.autograd.Function):
                 xr, xo = xs[:, :, src:src + n], x_out[:, dst:dst + n]
                 vr = None if vs is None else vs[:, :, src:src + n]
                 vo = None if v_out is None else v_out[:, dst:dst + n]
-                _lib.call("tcl_warp_fwd",
+                _lib.call("tcl_warp_fwd_fused",
                           _p(xr), xs.stride(0), xs.stride(2), xs.stride(1),
-                          _p(vr), vs.stride(0) if vs is not None else 0, vs.stride(2) if vs is not None else 0,
+                          _p(vr), vs.stride(0) if vs is not None else 0, vs.stride(2) if vs is not None else 0, int(bool(v_is_hole)),
                           _p(g_run), _p(t_run),
                           _p(xo), x_out.stride(0), x_out.stride(1), x_out.stride(2),
                           _p(vo), v_out.stride(0) if v_out is not None else 0, v_out.stride(1) if v_out is not None else 0,
+                          None, 0, 0, None, 0, 0,
                           b, n, c, h, w, int(align_corners), v_mode if vs is not None else _lib.VMODE_NONE, _stream(dev))
         ctx.save_for_backward(xs, gridc, thetac)
         ctx.align_corners = int(align_corners)
@@ -273,7 +292,33 @@ class WarpFn(torch.autograd.Function):
         if g_x is not None and ctx.gathered is not None:
             idx, f_all = ctx.gathered
             g_x = torch.zeros((b, c, f_all, h, w), dtype=torch.float32, device=dev).index_add_(2, idx, g_x)
-        return g_x, None, g_grid, g_theta, None, None, None
+        return g_x, None, g_grid, g_theta, None, None, None, None
+
+
+def align_infer(x_ref, m_ref, flow, m_target):
+    """The one-pair inference unit after the alignment network (thesis_dfpn/runner.py:157-158), ONE launch:
+    x_ref (B,3,F,H,W), m_ref (B,1,F,H,W) hole masks, flow (B,F,H,W,2), m_target (B,1,H,W) hole mask ->
+    x_aligned, v_aligned = align_set(x_ref, 1 - m_ref, flow) and v_map = clamp(v_aligned - (1 - m_target), 0, 1).
+    Not differentiable (the schedulers run it under no_grad); three-channel frames."""
+    dev = _require_device(x_ref, m_ref, flow, m_target)
+    b, c, f, h, w = x_ref.shape
+    if c != 3 or w < 2:
+        raise ValueError("align_infer takes three-channel frames at least two pixels wide")
+    xs, ms = _planes(x_ref.detach(), h, w), _planes(m_ref.detach(), h, w)
+    mt = m_target.detach().reshape(b, h, w)
+    mt = mt if (mt.stride(2) == 1 and mt.stride(1) == w) else mt.contiguous()
+    grid = flow.detach().reshape(b * f, h, w, 2)
+    grid = grid if grid.is_contiguous() else grid.contiguous()
+    out = torch.empty((b, f, 5, h, w), dtype=torch.float32, device=dev)   # one allocation: frames (3), visibility, v_map
+    x_out, v_out, v_map = out[:, :, 0:3], out[:, :, 3:4], out[:, :, 4:5]
+    with torch.cuda.device(dev):
+        _lib.call("tcl_warp_fwd_fused",
+                  _p(xs), xs.stride(0), xs.stride(2), xs.stride(1), _p(ms), ms.stride(0), ms.stride(2), 1,
+                  _p(grid), None,
+                  _p(x_out), out.stride(0), out.stride(1), out.stride(2), _p(v_out), out.stride(0), out.stride(1),
+                  _p(mt), mt.stride(0), 1, _p(v_map), out.stride(0), out.stride(1),
+                  b, f, 3, h, w, 1, _lib.VMODE_NEAREST, _stream(dev))
+    return x_out.transpose(1, 2), v_out.transpose(1, 2), v_map.transpose(1, 2)
 
 
 class AffineGridFn(torch.autograd.Function):
@@ -390,7 +435,7 @@ class ContextMatchingFn(torch.autograd.Function):
         p_in = torch.empty((b, cch + 1, h, w), dtype=torch.float32, device=dev)
         c_mask = torch.empty((b, 1, h, w), dtype=torch.float32, device=dev)
         c_match = torch.empty((b, r, h, w), dtype=torch.float32, device=dev)
-        ws = _workspace(_lib.lib().tcl_ctx_workspace_bytes(b, c, r, h, w), dev)
+        ws = _workspace(_lib.lib().tcl_ctx_workspace_bytes(b, c, r, h, w), dev, cache=not any(ctx.needs_input_grad))
         with torch.cuda.device(dev):
             _lib.call("tcl_ctx_fwd", _p(cf), _p(vt), _p(va), _p(p_in), _p(c_mask), _p(c_match), b, c, r, h, w, H, W,
                       variant, int(bool(normalize)), _p(ws), ws.numel(), _stream(dev))

@@ -23,6 +23,11 @@ struct WarpArgs {
   float stepx, stepy;  // 2/(W-1), 2/(H-1) (torch.linspace step), divided on the host
   int gf;              // frames per XCD unit (see warp_block): NF when the frames of a batch item share one source frame
   FastDiv fd_w, fd_nf; // / W (pixel -> row), / NF (image -> batch item)
+  // fused epilogue of the inference unit (tcl_warp_fwd_fused): v holds HOLE masks (visibility = 1 - v, flipped per tap);
+  // v_map = clamp(v_out - v_target, 0, 1) written beside v_out (T1, thesis_dfpn/runner.py:158)
+  int v_flip, vt_flip;
+  const float *vt; int64_t vt_sb;
+  float *vm; int64_t vm_sb, vm_sf;
 };
 
 // Grid (8, chunks per unit, units / 8) -> (image n, 256-pixel chunk).  Workgroups are dealt round-robin over the 8 XCDs in
@@ -164,10 +169,10 @@ constexpr int FWD_MAXC = 3;             // channels whose taps are fetched toget
 #endif
 template <bool HAS_THETA> struct FwdIters { static constexpr int value = HAS_THETA ? 1 : TCL_WARP_FWD_ITERS_GRID; };
 
-template <bool HAS_THETA, bool W2, int VMODE, bool C3>
+template <bool HAS_THETA, bool W2, int VMODE, bool C3, bool VMAP>
 __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chunk);
 
-template <bool HAS_THETA, bool W2, int VMODE, bool C3>
+template <bool HAS_THETA, bool W2, int VMODE, bool C3, bool VMAP = false>
 __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
   const int nchunk = (a.H * a.W + 255) >> 8;
   int n, cgroup;
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(WarpArgs a) {
 #pragma unroll 1
   for (int it = 0; it < ITERS; ++it) {
     const int chunk = cgroup * ITERS + it;
-    if (chunk < nchunk) warp_fwd_body<HAS_THETA, W2, VMODE, C3>(a, n, chunk);
+    if (chunk < nchunk) warp_fwd_body<HAS_THETA, W2, VMODE, C3, VMAP>(a, n, chunk);
   }
 }
 
@@ -206,7 +211,7 @@ __device__ __forceinline__ ShareTaps make_share(const Taps &t, int W, bool live)
 }
 struct PlaneTaps { float nw, ne, sw, se; };
 
-template <bool HAS_THETA, bool W2, int VMODE, bool C3>
+template <bool HAS_THETA, bool W2, int VMODE, bool C3, bool VMAP>
 __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chunk) {
   const int H = a.H, W = a.W;
   const int b = (int)a.fd_nf.div((unsigned)n), f = n - b * a.NF;
@@ -230,6 +235,17 @@ __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chun
   const float *vp = a.v + b * a.v_sb + f * a.v_sf;
   const float *xp = a.x + b * a.x_sb + f * a.x_sf;
   float *op = a.xo + b * a.xo_sb + f * a.xo_sf + pix;
+  const bool flip = a.v_flip != 0;
+  float vtgt = 0.f;
+  if (VMAP) vtgt = a.vt[b * a.vt_sb + pix];   // unconditional for this instantiation: in flight with the taps
+  // visibility value -> v_out (and v_map = clamp(v - v_target, 0, 1), v_target = 1 - hole mask when vt_flip)
+  auto put_v = [&](float vr) {
+    st_stream(a.vo + b * a.vo_sb + f * a.vo_sf + pix, vr);
+    if (VMAP) {
+      const float vt1 = a.vt_flip ? __fsub_rn(1.f, vtgt) : vtgt;
+      st_stream(a.vm + b * a.vm_sb + f * a.vm_sf + pix, fminf(fmaxf(__fsub_rn(vr, vt1), 0.f), 1.f));
+    }
+  };
   // Measured (round 3, cache-cold legs, A/B in the same runs): align_set (grid source, nearest visibility) 65.8 -> 63.9 us with
   // the shared taps; the affine forward (theta source, bilinear visibility: 8 west + 8 masked east loads instead of 8 gathers)
   // 0.261 -> 0.308 ms, i.e. that kernel pays per vector-memory INSTRUCTION, not per byte the L1 returns.  So: grid sources only.
@@ -260,10 +276,11 @@ __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chun
       en[p] = s.share ? nn : en[p];
       es[p] = s.share ? ns : es[p];
     }
-    if (VMODE == TCL_VMODE_NEAREST) { if (ok) st_stream(a.vo + b * a.vo_sb + f * a.vo_sf + pix, inb ? vnear : 0.f); }
+    if (VMODE == TCL_VMODE_NEAREST) { if (ok) put_v(inb ? (flip ? __fsub_rn(1.f, vnear) : vnear) : 0.f); }
     else if (VB) {
-      const float vr = blend((t.yn & t.xw) ? wn[3] : 0.f, (t.yn & t.xe) ? en[3] : 0.f, (t.ys & t.xw) ? ws[3] : 0.f, (t.ys & t.xe) ? es[3] : 0.f, t);
-      if (ok) st_stream(a.vo + b * a.vo_sb + f * a.vo_sf + pix, vr > 0.5f ? 1.f : 0.f);
+      if (flip) { wn[NP - 1] = __fsub_rn(1.f, wn[NP - 1]); en[NP - 1] = __fsub_rn(1.f, en[NP - 1]); ws[NP - 1] = __fsub_rn(1.f, ws[NP - 1]); es[NP - 1] = __fsub_rn(1.f, es[NP - 1]); }
+      const float vr = blend((t.yn & t.xw) ? wn[NP - 1] : 0.f, (t.yn & t.xe) ? en[NP - 1] : 0.f, (t.ys & t.xw) ? ws[NP - 1] : 0.f, (t.ys & t.xe) ? es[NP - 1] : 0.f, t);
+      if (ok) put_v(vr > 0.5f ? 1.f : 0.f);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -292,13 +309,14 @@ __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chun
   // ---- visibility
   if (VMODE != TCL_VMODE_NONE) {
     float vr;
-    if (VMODE == TCL_VMODE_NEAREST) vr = inb ? vnear : 0.f;
+    if (VMODE == TCL_VMODE_NEAREST) vr = inb ? (flip ? __fsub_rn(1.f, vnear) : vnear) : 0.f;
     else {
+      if (flip) { tvv.n.a = __fsub_rn(1.f, tvv.n.a); tvv.n.b = __fsub_rn(1.f, tvv.n.b); tvv.s.a = __fsub_rn(1.f, tvv.s.a); tvv.s.b = __fsub_rn(1.f, tvv.s.b); }
       float p, q, r, s;
       select_taps<W2>(tvv, t, p, q, r, s);
       vr = blend(p, q, r, s, t) > 0.5f ? 1.f : 0.f;
     }
-    st_stream(a.vo + b * a.vo_sb + f * a.vo_sf + pix, vr);
+    put_v(vr);
   }
   // ---- image channels
   if (C3) {
@@ -713,6 +731,15 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
                             int64_t v_sf, const float *grid, const float *theta, float *x_out, int64_t xo_sb,
                             int64_t xo_sf, int64_t xo_sc, float *v_out, int64_t vo_sb, int64_t vo_sf, int64_t NB,
                             int64_t NF, int64_t C, int64_t H, int64_t W, int align_corners, int v_mode, void *stream) {
+  return tcl_warp_fwd_fused(x, x_sb, x_sf, x_sc, v, v_sb, v_sf, 0, grid, theta, x_out, xo_sb, xo_sf, xo_sc, v_out, vo_sb, vo_sf, nullptr, 0, 0,
+                            nullptr, 0, 0, NB, NF, C, H, W, align_corners, v_mode, stream);
+}
+
+extern "C" int tcl_warp_fwd_fused(const float *x, int64_t x_sb, int64_t x_sf, int64_t x_sc, const float *v, int64_t v_sb,
+                                  int64_t v_sf, int v_is_hole_mask, const float *grid, const float *theta, float *x_out, int64_t xo_sb,
+                                  int64_t xo_sf, int64_t xo_sc, float *v_out, int64_t vo_sb, int64_t vo_sf,
+                                  const float *v_target, int64_t vt_sb, int vt_is_hole_mask, float *v_map, int64_t vm_sb, int64_t vm_sf,
+                                  int64_t NB, int64_t NF, int64_t C, int64_t H, int64_t W, int align_corners, int v_mode, void *stream) {
   TCL_REQUIRE(NB > 0 && NF > 0 && H > 0 && W > 0 && C >= 0, TCL_ERR_SHAPE, "tcl_warp_fwd: bad shape NB=%ld NF=%ld C=%ld H=%ld W=%ld",
               (long)NB, (long)NF, (long)C, (long)H, (long)W);
   TCL_REQUIRE((grid != nullptr) != (theta != nullptr), TCL_ERR_ARG, "tcl_warp_fwd: exactly one of grid / theta must be given");
@@ -727,13 +754,18 @@ extern "C" int tcl_warp_fwd(const float *x, int64_t x_sb, int64_t x_sf, int64_t 
               "tcl_warp_fwd: too many images for one launch (%ld) or image too large", (long)(NB * NF));
   WarpArgs a{x, x_sb, x_sf, x_sc, v, v_sb, v_sf, grid, theta, x_out, xo_sb, xo_sf, xo_sc, v_out, vo_sb, vo_sf,
              (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, v_mode, lin_step(W), lin_step(H), (int)gf,
-             make_fastdiv((uint32_t)W), make_fastdiv((uint32_t)NF)};
+             make_fastdiv((uint32_t)W), make_fastdiv((uint32_t)NF), v_is_hole_mask != 0, vt_is_hole_mask != 0, v_target, vt_sb, v_map, vm_sb, vm_sf};
+  TCL_REQUIRE((v_target != nullptr) == (v_map != nullptr), TCL_ERR_ARG, "tcl_warp_fwd_fused: v_target and v_map go together");
+  TCL_REQUIRE(!v_map || (v_mode != TCL_VMODE_NONE && x_out != nullptr && C == 3 && W >= 2), TCL_ERR_UNSUPPORTED,
+              "tcl_warp_fwd_fused: the fused v_map needs a visibility mode, 3-channel frames and W >= 2");
+  const bool vmap = v_map != nullptr;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grd = warp_grid(cdiv(cdiv(H * W, 256), theta ? FwdIters<true>::value : FwdIters<false>::value), a.gf, NB * NF), blk(256);
   const bool c3 = x_out != nullptr && C == 3;
 #define TCL_LAUNCH_WARP(TH, W2, VM)                                                                  \
   do {                                                                                                \
-    if (c3) hipLaunchKernelGGL((warp_fwd_kernel<TH, W2, VM, true>), grd, blk, 0, s, a);               \
+    if (vmap && W2 && VM != TCL_VMODE_NONE) hipLaunchKernelGGL((warp_fwd_kernel<TH, W2, VM, true, W2 && VM != TCL_VMODE_NONE>), grd, blk, 0, s, a); \
+    else if (c3) hipLaunchKernelGGL((warp_fwd_kernel<TH, W2, VM, true>), grd, blk, 0, s, a);          \
     else hipLaunchKernelGGL((warp_fwd_kernel<TH, W2, VM, false>), grd, blk, 0, s, a);                 \
   } while (0)
 #define TCL_LAUNCH_WARP_V(TH, W2)                                                                    \

@@ -60,7 +60,8 @@ def affine_align(x, m, y, theta_rt, r_list, training=False):
     # the reference gathers x[:, :, r_list] / m[:, :, r_list] first (an index copy as long as the warp itself); here the warp
     # reads the reference frames in place (WarpFn's `frames`)
     frames = [int(i) for i in r_list]
-    x_aligned, v_aligned = _ops.WarpFn.apply(x, 1 - m, None, theta_rt, False, _lib.VMODE_BILINEAR_THRESHOLD, frames)
+    # ... and flips the hole masks per tap (v_is_hole): no `1 - m` over all R + 1 frames either
+    x_aligned, v_aligned = _ops.WarpFn.apply(x, m, None, theta_rt, False, _lib.VMODE_BILINEAR_THRESHOLD, frames, True)
     y_aligned = None
     if not training and y is not None:
         y_aligned, _ = _ops.WarpFn.apply(y, None, None, theta_rt, False, _lib.VMODE_NONE, frames)

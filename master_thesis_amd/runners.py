@@ -65,6 +65,10 @@ def infer_step_propagate(model, x_target, m_target, x_ref, m_ref):
     """thesis_dfpn/runner.py:153-159: the unit the FF / IP / CP sequence schedulers call once per (target, reference) pair."""
     with torch.no_grad():
         *_, flow_256 = model(x_target, m_target, x_ref, m_ref)
+    if x_ref.is_cuda and x_ref.size(1) == 3 and x_ref.size(-1) >= 2:
+        # align_set + both `1 - m` + v_map in ONE launch (tcl_warp_fwd_fused): the schedulers call this unit thousands of times
+        # per sequence at batch 1, where every extra kernel and tensor is host time
+        return _ops.align_infer(x_ref, m_ref, flow_256, m_target)
     x_ref_aligned, v_ref_aligned = flow_ops.align_set(x_ref, 1 - m_ref, flow_256)
     v_map = _ops.vmap(v_ref_aligned, 1 - m_target)
     return x_ref_aligned, v_ref_aligned, v_map

@@ -772,3 +772,43 @@ def test_warp_frames_equals_gathered_frames(mods, frames, use_theta):
     assert_exact(b[1], a[1], what="v_out")
     assert_close(b[2], a[2], rtol=1e-6, atol=1e-6, what="g_x")        # float atomics: summation order
     assert_close(b[3], a[3], rtol=1e-5, atol=1e-6, what="g_theta / g_grid")
+
+
+@pytest.mark.parametrize("B,F,H,W", [(1, 1, 240, 480), (2, 3, 33, 47), (3, 2, 64, 64)])
+def test_align_infer_equals_the_unfused_unit(mods, B, F, H, W):
+    """tcl_warp_fwd_fused (hole masks flipped per tap, v_map in the epilogue) == align_set(x, 1 - m, flow) followed by
+    clamp(v_aligned - (1 - m_target), 0, 1) (thesis_dfpn/runner.py:157-158), bit for bit, and == the oracle; strided inputs too."""
+    from master_thesis_amd import _ops
+    rng = np.random.default_rng(B * 100 + W)
+    x = rng.random((B, 3, F + 2, H, W)).astype(np.float32)
+    m = (rng.random((B, 1, F + 2, H, W)) < 0.3).astype(np.float32)
+    mt = (rng.random((B, 1, H, W)) < 0.3).astype(np.float32)
+    flow = (rng.random((B, F, H, W, 2)) * 2.3 - 1.15).astype(np.float32)
+    tx, tm = T(x)[:, :, 1:F + 1], T(m)[:, :, 1:F + 1]          # views into larger tensors (the schedulers slice frames)
+    xa, va, vm = _ops.align_infer(tx, tm, T(flow), T(mt))
+    xa0, va0 = mods["flow"].align_set(tx, 1 - tm, T(flow))
+    vm0 = _ops.vmap(va0, 1 - T(mt))
+    assert_exact(N(xa), N(xa0), what="x_aligned")
+    assert_exact(N(va), N(va0), what="v_aligned")
+    assert_exact(N(vm), N(vm0), what="v_map")
+    oxa, ova = O.align_set(x[:, :, 1:F + 1], 1 - m[:, :, 1:F + 1], flow)
+    assert_close(N(xa), oxa, what="x_aligned vs oracle")
+    assert_exact(N(va), ova, what="v_aligned vs oracle")
+    assert_exact(N(vm), np.clip(ova - (1 - mt)[:, :, None], 0, 1), what="v_map vs oracle")
+
+
+def test_warp_hole_mask_flip_equals_one_minus_m():
+    """WarpFn(..., v_is_hole=True) on m == WarpFn on 1 - m, both visibility modes, theta and grid sources."""
+    from master_thesis_amd import _lib, _ops
+    rng = np.random.default_rng(31)
+    B, F, H, W = 2, 3, 40, 72
+    x = rng.random((B, 3, F, H, W)).astype(np.float32)
+    m = (rng.random((B, 1, F, H, W)) < 0.4).astype(np.float32)
+    theta = (np.tile(np.eye(2, 3, dtype=np.float32), (B * F, 1, 1)) + 0.1 * rng.standard_normal((B * F, 2, 3))).astype(np.float32)
+    flow = (rng.random((B * F, H, W, 2)) * 2.2 - 1.1).astype(np.float32)
+    for grid, th, ac, mode in ((None, T(theta), False, _lib.VMODE_BILINEAR_THRESHOLD), (T(flow), None, True, _lib.VMODE_NEAREST),
+                               (T(flow), None, True, _lib.VMODE_BILINEAR_THRESHOLD), (None, T(theta), False, _lib.VMODE_NEAREST)):
+        xa, va = _ops.WarpFn.apply(T(x), T(m), grid, th, ac, mode, None, True)
+        xb, vb = _ops.WarpFn.apply(T(x), 1 - T(m), grid, th, ac, mode)
+        assert_exact(N(xa), N(xb), what="x")
+        assert_exact(N(va), N(vb), what="v")
