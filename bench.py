@@ -391,85 +391,157 @@ def _legs_infer(dev, legs, stream):
         "wall_reduction": round(1 - w_f / w_u, 3)}
 
 
-# ------------------------------------------------------------------------------------------------ CPU baseline (numpy oracle)
-def cpu_baseline(budget_s=24.0):
-    """The numpy oracle on the host cores, per leg, on bounded samples of the same workload; composite pairs/s = 1 / sum of the
-    legs' seconds per pair.  `cores`: the BLAS threads the correlation GEMMs used (everything else in numpy is one thread);
-    `one_thread`: the same with BLAS limited to one thread."""
+# ------------------------------------------------------------------------------------------------ CPU baseline (torch CPU, oracle-checked)
+def _cpu_corr(xt, vt, xr, vr):
+    """utils/correlation.py:28-54 as stock torch ops (multi-threaded ATen): mask, L2-normalise over C, batched matmul."""
+    b, c, f, h, w = xr.shape
+    t = (xt * vt).reshape(b, c, h * w).transpose(1, 2)
+    t = t / (t.norm(dim=2, keepdim=True) + 1e-9)
+    r = (xr * vr).reshape(b, c, f, h * w).permute(0, 2, 1, 3)
+    r = r / (r.norm(dim=2, keepdim=True) + 1e-9)
+    return torch.matmul(t.unsqueeze(1), r).reshape(b, f, h, w, h, w)
+
+
+def _cpu_align_set(x, v, flow):
+    """utils/flow.py:93-101 as stock torch ops."""
+    import torch.nn.functional as F
+    b, c, f, h, w = x.shape
+    grid = flow.reshape(b * f, h, w, 2)
+    xa = F.grid_sample(x.transpose(1, 2).reshape(b * f, c, h, w), grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    va = F.grid_sample(v.transpose(1, 2).reshape(b * f, 1, h, w), grid, mode="nearest", padding_mode="zeros", align_corners=True)
+    return xa.reshape(b, f, c, h, w).transpose(1, 2), va.reshape(b, f, 1, h, w).transpose(1, 2)
+
+
+def _cpu_affine_align(x, m, theta, r_list):
+    """models/cpn.py:280-290 as stock torch ops."""
+    import torch.nn.functional as F
+    b, c, _, h, w = x.shape
+    r = len(r_list)
+    grid = F.affine_grid(theta, (b * r, c, h, w), align_corners=False)
+    xa = F.grid_sample(x[:, :, r_list].transpose(1, 2).reshape(b * r, c, h, w), grid, align_corners=False)
+    va = (F.grid_sample((1 - m[:, :, r_list]).transpose(1, 2).reshape(b * r, 1, h, w), grid, align_corners=False) > 0.5).float()
+    return xa.reshape(b, r, c, h, w).transpose(1, 2), va.reshape(b, r, 1, h, w).transpose(1, 2)
+
+
+def _cpu_context_matching(cf, v_t, v_al):
+    """models/cpn.py:94-135 (normalize=False) vectorised over the references, stock torch ops; ref_importance = the bilinear
+    upsample of the weights (the border drawing of add_match_border is left out)."""
+    import torch.nn.functional as F
+    b, c, f, h, w = cf.shape
+    r = f - 1
+    H, W = v_t.shape[-2:]
+    vt = (F.interpolate(v_t, size=(h, w), mode="bilinear", align_corners=False) > 0.5).float()                      # (b,1,h,w)
+    vr = (F.interpolate(v_al.reshape(b, r, H, W), size=(h, w), mode="bilinear", align_corners=False) > 0.5).float()  # (b,r,h,w)
+    vmap = vt * vr
+    v_sum = vmap.sum(dim=(2, 3))
+    zeros = v_sum < 1e-4
+    gs = (vmap.unsqueeze(1) * cf[:, :, :1] * cf[:, :, 1:]).sum(dim=(1, 3, 4))                                        # (b,r)
+    gs = torch.where(zeros, torch.zeros_like(gs), gs)
+    mv = gs[:, :, None, None] * vr                                                                                   # masked_softmax, dim = refs
+    e = torch.exp(mv - mv.max(dim=1, keepdim=True)[0]) * vr
+    ssum = e.sum(dim=1, keepdim=True)
+    ssum = ssum + (ssum < 1e-4).float()
+    c_match = e / ssum                                                                                                # (b,r,h,w)
+    c_out = (cf[:, :, 1:] * c_match.unsqueeze(1)).sum(dim=2)
+    c_mask = 1 - (c_match * vr).sum(dim=1, keepdim=True)
+    imp = F.interpolate(c_match, size=(H, W), mode="bilinear", align_corners=False).unsqueeze(1).expand(b, 3, r, H, W).contiguous()
+    return torch.cat([cf[:, :, 0], c_out, c_mask], dim=1), c_mask, imp
+
+
+def cpu_baseline(budget_s=26.0):
+    """The three legs as stock torch-CPU ops (ATen's multi-threaded matmul / grid_sample / interpolate kernels: what the
+    reference's own CPU path executes), written here, forward + backward through torch.autograd, on bounded samples of the
+    bench's shapes; every leg is first checked against the numpy oracle (the checker, not the thing timed).  Timed with all
+    threads torch uses on this host and with one; composite pairs/s = 1 / sum of the legs' seconds per pair."""
     from oracle import tcl_oracle as O
-    try:
-        from threadpoolctl import threadpool_info, threadpool_limits
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        threadpool_limits, cores = None, int(os.environ.get("OMP_NUM_THREADS", "1"))
-    rng = np.random.default_rng(1234)
-    C, F, S = CORR["C"], CORR["F"], CORR["S"]
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    C, F_, S = CORR["C"], CORR["F"], CORR["S"]
     nb = 2
-    xt = rng.standard_normal((nb, C, S, S)).astype(np.float32)
-    xr = rng.standard_normal((nb, C, F, S, S)).astype(np.float32)
-    vt = (rng.random((nb, 1, S, S)) >= 0.1).astype(np.float32)
-    vr = (rng.random((nb, 1, F, S, S)) >= 0.1).astype(np.float32)
-    cot = rng.standard_normal((nb, F, S, S, S, S)).astype(np.float32)
+    xt = torch.randn(nb, C, S, S, generator=g, requires_grad=True)
+    xr = torch.randn(nb, C, F_, S, S, generator=g, requires_grad=True)
+    vt = (torch.rand(nb, 1, S, S, generator=g) >= 0.1).float()
+    vr = (torch.rand(nb, 1, F_, S, S, generator=g) >= 0.1).float()
+    cot = torch.randn(nb, F_, S, S, S, S, generator=g)
 
     def corr():
-        O.compute_masked_4d_correlation(xt, vt, xr, vr)
-        O.compute_masked_4d_correlation_bwd(xt, vt, xr, vr, cot)
-        return nb * F
+        out = _cpu_corr(xt, vt, xr, vr)
+        torch.autograd.grad(out, [xt, xr], grad_outputs=cot)
+        return nb * F_
 
     s = 256
-    x = rng.random((1, 3, 2, s, s)).astype(np.float32)
-    v = (rng.random((1, 1, 2, s, s)) < 0.85).astype(np.float32)
-    ident = np.stack(np.meshgrid(np.linspace(-1, 1, s), np.linspace(-1, 1, s)), axis=-1).astype(np.float32)
-    fl = (ident[None, None] * 1.05 + 0.1).repeat(2, axis=1).astype(np.float32)
-    cw = rng.standard_normal(x.shape).astype(np.float32)
+    x = torch.rand(2, 3, 4, s, s, generator=g)
+    v = (torch.rand(2, 1, 4, s, s, generator=g) < 0.85).float()
+    fl_gt = (_ident(s)[None, None] * 1.05 + 0.1).repeat(2, 4, 1, 1, 1).contiguous()
+    fl_pr = (_ident(s)[None, None] * 0.97 - 0.05).repeat(2, 4, 1, 1, 1).contiguous().requires_grad_(True)
+    cw = torch.randn(2, 3, 4, s, s, generator=g)
 
-    def warp():   # per pair at 256 px: two forward warps (ground-truth and predicted flow) and one backward; 16 / 64 px add 7 %
-        O.align_set(x, v, fl)
-        O.align_set(x, v, fl)
-        O.align_set_bwd(x, v, fl, cw)
-        return 2
+    def warp():   # per pair at 256 px: the ground-truth-flow warp, the predicted-flow warp and its grid-gradient backward; 16 / 64 px add 7 %
+        with torch.no_grad():
+            _cpu_align_set(x, v, fl_gt)
+        xa, _ = _cpu_align_set(x, v, fl_pr)
+        torch.autograd.grad(xa, [fl_pr], grad_outputs=cw)
+        return 8
 
     B, Cc, R, h, w, H, W = 1, C4["C"], C4["R"], C4["h"], C4["w"], C4["H"], C4["W"]
     r_list = [i for i in range(R + 1) if i != R // 2]
-    x4 = rng.random((B, 3, R + 1, H, W)).astype(np.float32)
-    m4 = (rng.random((B, 1, R + 1, H, W)) < 0.15).astype(np.float32)
-    th = (np.array([[1, 0, 0], [0, 1, 0]], np.float32)[None] + 0.05 * rng.standard_normal((B * R, 2, 3))).astype(np.float32)
-    cf = (0.05 * rng.standard_normal((B, Cc, R + 1, h, w))).astype(np.float32)
-    cx = rng.standard_normal((B, 3, R, H, W)).astype(np.float32)
-    cp, cm = rng.standard_normal((B, 2 * Cc + 1, h, w)).astype(np.float32), np.zeros((B, 1, h, w), np.float32)
+    x4 = torch.rand(B, 3, R + 1, H, W, generator=g)
+    m4 = (torch.rand(B, 1, R + 1, H, W, generator=g) < 0.15).float()
+    th = (torch.tensor([[1.0, 0, 0], [0, 1.0, 0]]) + 0.05 * torch.randn(B * R, 2, 3, generator=g)).requires_grad_(True)
+    cf = (0.05 * torch.randn(B, Cc, R + 1, h, w, generator=g)).requires_grad_(True)
+    cx = torch.randn(B, 3, R, H, W, generator=g)
+    cp = torch.randn(B, 2 * Cc + 1, h, w, generator=g)
 
     def match():
-        _, va, _ = O.cpn_align(x4, m4, None, th, r_list)
-        O.cpn_align_bwd(x4, th, r_list, cx)
-        O.context_matching(cf, 1 - m4[:, :, R // 2], va, False, "default")
-        O.context_matching_bwd(cf, 1 - m4[:, :, R // 2], va, cp, cm, False, "default")
+        xa, va = _cpu_affine_align(x4, m4, th, r_list)
+        p_in, c_mask, imp = _cpu_context_matching(cf, 1 - m4[:, :, R // 2], va)
+        torch.autograd.grad([xa, p_in], [th, cf], grad_outputs=[cx, cp])
         return R
+
+    # ---- the oracle as the checker of what is about to be timed
+    n = lambda t: t.detach().numpy()
+    checks = {}
+    out = _cpu_corr(xt[:1], vt[:1], xr[:1], vr[:1])
+    checks["corr"] = bool(np.allclose(n(out), O.compute_masked_4d_correlation(n(xt[:1]), n(vt[:1]), n(xr[:1]), n(vr[:1])), rtol=1e-4, atol=1e-5))
+    xa, va = _cpu_align_set(x[:1, :, :1], v[:1, :, :1], fl_pr[:1, :1])
+    oxa, ova = O.align_set(n(x[:1, :, :1]), n(v[:1, :, :1]), n(fl_pr[:1, :1]))
+    checks["warp"] = bool(np.allclose(n(xa), oxa, rtol=1e-4, atol=1e-5) and np.array_equal(n(va), ova))
+    xa, va = _cpu_affine_align(x4, m4, th, r_list)
+    oxa, ova, _ = O.cpn_align(n(x4), n(m4), None, n(th), r_list)
+    p_in, c_mask, _ = _cpu_context_matching(cf, 1 - m4[:, :, R // 2], torch.from_numpy(ova))
+    op, om, _ = O.context_matching(n(cf), n(1 - m4[:, :, R // 2]), ova, False, "default")
+    # ATen's vectorised CPU grid_sample un-normalises as (g + 1) * (W / 2) - 0.5 (one fp32 ulp off the scalar / GPU formula near
+    # x = 400: DESIGN.md section 2), hence 2e-4 absolute on the frames and a 1e-4 fraction of threshold flips on the visibility
+    checks["match"] = bool(np.allclose(n(xa), oxa, rtol=1e-4, atol=2e-4) and np.mean(n(va) != ova) < 1e-4 and
+                           np.allclose(n(p_in), op, rtol=1e-4, atol=1e-5) and np.allclose(n(c_mask), om, rtol=1e-4, atol=1e-5))
 
     def rate(fn, budget):
         fn()
-        t0, n = time.perf_counter(), 0
+        t0, cnt = time.perf_counter(), 0
         while True:
-            n += fn()
+            cnt += fn()
             el = time.perf_counter() - t0
             if el > budget:
-                return n / el, n, el
+                return cnt / el, cnt, el
 
-    share = budget_s / 4.5
-    legs, sample = {}, []
-    for name, fn, b in (("corr", corr, share * 1.5), ("warp", warp, share), ("match", match, share)):
-        r, n, el = rate(fn, b)
-        legs[name] = round(r, 3)
-        sample.append("%s: %d pairs in %.1f s" % (name, n, el))
-    composite = 1.0 / sum(1.0 / legs[k] for k in legs)
-    res = dict(value=round(composite, 3), unit="pairs/s", cores=int(cores), kind="port", legs_pairs_per_s=legs,
-               sample="numpy oracle, fwd+bwd per leg at the bench's shapes (" + "; ".join(sample) + "); composite = 1 / sum of seconds per pair")
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            r1, n, el = rate(corr, share)
-        one = dict(legs)
-        one["corr"] = round(r1, 3)
-        res["one_thread"] = dict(value=round(1.0 / sum(1.0 / one[k] for k in one), 3), legs_pairs_per_s=one, cores=1)
-    return res
+    all_threads = torch.get_num_threads()
+    share = budget_s / 8.0
+    res = {}
+    for label, nthreads, scale in (("all", all_threads, 1.5), ("one", 1, 1.0)):
+        torch.set_num_threads(nthreads)
+        legs, sample = {}, []
+        for name, fn, bsec in (("corr", corr, share * scale * 1.3), ("warp", warp, share * scale * 0.85), ("match", match, share * scale * 0.85)):
+            r, cnt, el = rate(fn, bsec)
+            legs[name] = round(r, 3)
+            sample.append("%s: %d pairs in %.1f s" % (name, cnt, el))
+        res[label] = dict(value=round(1.0 / sum(1.0 / legs[k] for k in legs), 3), legs_pairs_per_s=legs, cores=nthreads, sample="; ".join(sample))
+    torch.set_num_threads(all_threads)
+    a = res["all"]
+    return dict(value=a["value"], unit="pairs/s", cores=a["cores"], kind="port", legs_pairs_per_s=a["legs_pairs_per_s"],
+                cores_per_leg={k: a["cores"] for k in a["legs_pairs_per_s"]},
+                sample="stock torch-CPU ops (ATen matmul / grid_sample / interpolate + autograd, written in bench.py), fwd+bwd per leg at the "
+                       "bench's shapes (" + a["sample"] + "); composite = 1 / sum of seconds per pair; every leg checked against the numpy oracle first",
+                oracle_check=checks, one_thread=dict(value=res["one"]["value"], legs_pairs_per_s=res["one"]["legs_pairs_per_s"], cores=1,
+                                                     sample=res["one"]["sample"]))
 
 
 # ------------------------------------------------------------------------------------------------ main
