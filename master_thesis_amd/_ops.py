@@ -295,30 +295,38 @@ class WarpFn(torch.autograd.Function):
         return g_x, None, g_grid, g_theta, None, None, None, None
 
 
-def align_infer(x_ref, m_ref, flow, m_target):
-    """The one-pair inference unit after the alignment network (thesis_dfpn/runner.py:157-158), ONE launch:
-    x_ref (B,3,F,H,W), m_ref (B,1,F,H,W) hole masks, flow (B,F,H,W,2), m_target (B,1,H,W) hole mask ->
-    x_aligned, v_aligned = align_set(x_ref, 1 - m_ref, flow) and v_map = clamp(v_aligned - (1 - m_target), 0, 1).
-    Not differentiable (the schedulers run it under no_grad); three-channel frames."""
-    dev = _require_device(x_ref, m_ref, flow, m_target)
+def warp_infer(x_ref, m_ref, m_target, grid=None, theta=None, align_corners=True, v_mode=None):
+    """Inference-only warp of reference frames with everything around it in ONE launch (tcl_warp_fwd_fused):
+    x_ref (B,3,F,H,W), m_ref (B,1,F,H,W) HOLE masks, m_target (B,1,H,W) hole mask, positions from `grid` (B*F,H,W,2) or
+    `theta` (B*F,2,3) -> x_aligned (B,3,F,H,W), v_aligned = warp(1 - m_ref) (B,1,F,H,W), v_map = clamp(v_aligned - (1 - m_target), 0, 1).
+    Not differentiable (the callers run it under no_grad); three-channel frames."""
+    dev = _require_device(x_ref, m_ref, grid, theta, m_target)
     b, c, f, h, w = x_ref.shape
     if c != 3 or w < 2:
-        raise ValueError("align_infer takes three-channel frames at least two pixels wide")
+        raise ValueError("warp_infer takes three-channel frames at least two pixels wide")
+    if (grid is None) == (theta is None):
+        raise ValueError("exactly one of grid / theta")
     xs, ms = _planes(x_ref.detach(), h, w), _planes(m_ref.detach(), h, w)
     mt = m_target.detach().reshape(b, h, w)
     mt = mt if (mt.stride(2) == 1 and mt.stride(1) == w) else mt.contiguous()
-    grid = flow.detach().reshape(b * f, h, w, 2)
-    grid = grid if grid.is_contiguous() else grid.contiguous()
+    gridc = None if grid is None else grid.detach().reshape(b * f, h, w, 2).contiguous()
+    thetac = None if theta is None else theta.detach().reshape(b * f, 2, 3).contiguous()
     out = torch.empty((b, f, 5, h, w), dtype=torch.float32, device=dev)   # one allocation: frames (3), visibility, v_map
     x_out, v_out, v_map = out[:, :, 0:3], out[:, :, 3:4], out[:, :, 4:5]
     with torch.cuda.device(dev):
         _lib.call("tcl_warp_fwd_fused",
                   _p(xs), xs.stride(0), xs.stride(2), xs.stride(1), _p(ms), ms.stride(0), ms.stride(2), 1,
-                  _p(grid), None,
+                  _p(gridc), _p(thetac),
                   _p(x_out), out.stride(0), out.stride(1), out.stride(2), _p(v_out), out.stride(0), out.stride(1),
                   _p(mt), mt.stride(0), 1, _p(v_map), out.stride(0), out.stride(1),
-                  b, f, 3, h, w, 1, _lib.VMODE_NEAREST, _stream(dev))
+                  b, f, 3, h, w, int(bool(align_corners)), _lib.VMODE_NEAREST if v_mode is None else v_mode, _stream(dev))
     return x_out.transpose(1, 2), v_out.transpose(1, 2), v_map.transpose(1, 2)
+
+
+def align_infer(x_ref, m_ref, flow, m_target):
+    """The one-pair inference unit after the alignment network (thesis_dfpn/runner.py:157-158):
+    align_set(x_ref, 1 - m_ref, flow) and v_map = clamp(v_aligned - (1 - m_target), 0, 1), one launch."""
+    return warp_infer(x_ref, m_ref, m_target, grid=flow, align_corners=True, v_mode=_lib.VMODE_NEAREST)
 
 
 class AffineGridFn(torch.autograd.Function):

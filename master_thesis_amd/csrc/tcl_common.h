@@ -35,36 +35,20 @@ constexpr float kNormEps = 1e-9f;
 
 // Streaming (non-temporal) stores for outputs the producing kernel never reads back: the lines bypass the L2's
 // write-allocate path instead of evicting operands (measured: ref_importance 114 -> 76 us, 3.8 -> 5.7 TB/s).
-// TCL_NO_STREAM_STORES turns them back into plain stores (A/B switch).  Non-temporal LOADS of once-read operands (grids,
+// (A/B of round 1: align_set fwd 4.9 -> 5.7 TB/s, context matching fwd + ref_importance 0.302 -> 0.242 ms.)  Non-temporal LOADS of once-read operands (grids,
 // incoming gradients) were measured too: 7 % slower in the warp forward, noise elsewhere, so loads stay plain.
 typedef float tcl_f2 __attribute__((ext_vector_type(2)));
 typedef float tcl_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_stream(float *p, float v) {
-#ifdef TCL_ABL_NOSTORE   // diagnostic side build: keep the value alive, store (almost) never
-  if (v == 1.2345e-30f) *p = v;
-  return;
-#endif
-#ifdef TCL_NO_STREAM_STORES
-  *p = v;
-#else
   __builtin_nontemporal_store(v, p);
-#endif
 }
 __device__ __forceinline__ void st_stream2(float *p, float a, float b) {
-#ifdef TCL_NO_STREAM_STORES
-  *reinterpret_cast<float2 *>(p) = make_float2(a, b);
-#else
   const tcl_f2 v = {a, b};
   __builtin_nontemporal_store(v, reinterpret_cast<tcl_f2 *>(p));
-#endif
 }
 __device__ __forceinline__ void st_stream4(float *p, float a, float b, float c, float d) {
-#ifdef TCL_NO_STREAM_STORES
-  *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
-#else
   const tcl_f4 v = {a, b, c, d};
   __builtin_nontemporal_store(v, reinterpret_cast<tcl_f4 *>(p));
-#endif
 }
 
 // wave64 reductions
@@ -94,9 +78,6 @@ static inline FastDiv make_fastdiv(uint32_t d) {
 // Bijective XCD-aware remap of a 1-D block id: blocks are dealt round-robin over the 8 XCDs, so give each
 // XCD a contiguous chunk of the logical tile order (neighbouring tiles then share one L2).
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
-#ifdef TCL_NO_XCD_REMAP
-  return bid;
-#endif
   const unsigned q = nblk / kNumXCD, r = nblk % kNumXCD;
   const unsigned xcd = bid % kNumXCD, idx = bid / kNumXCD;
   const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;

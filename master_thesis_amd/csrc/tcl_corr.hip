@@ -389,18 +389,10 @@ struct TileLoader {
   }
 
   // Full tiles (M, N multiples of the block tile, K of BK, 16-byte aligned rows): no bounds, no per-load 64-bit index
-  // arithmetic.  `p0` = this thread's first float4 of the operand's k-tile 0 (thread_base); float4 i sits a block-uniform
-  // `i * step(ld)` floats further, the next k-tile `kstep(ld)` floats further.
-  __device__ __forceinline__ static const float *thread_base(const float *base, int64_t ld, int row0, int tid) {
-    if (KC) return base + (int64_t)(row0 + tid / (BK / 4)) * ld + (tid % (BK / 4)) * 4;
-    return base + (int64_t)(tid / (ROWS / 4)) * ld + row0 + (tid % (ROWS / 4)) * 4;
-  }
+  // arithmetic.  float4 i of a thread sits a block-uniform `step(ld)` floats behind float4 i - 1, the next k-tile `kstep(ld)`
+  // floats further.
   __device__ __forceinline__ static int64_t step(int64_t ld) { return KC ? (NT / (BK / 4)) * ld : (NT / (ROWS / 4)) * ld; }
   __device__ __forceinline__ static int64_t kstep(int64_t ld) { return KC ? BK : BK * ld; }
-  __device__ __forceinline__ void load_full(const float *p0, int64_t st) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const f32x4 *>(p0 + i * st);
-  }
   // The same loads as `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen`: a descriptor on the operand's (row0, k-tile 0)
   // element, loop-invariant per-thread 32-bit byte offsets, and the k-tile as a scalar byte offset: no vector address
   // arithmetic per load (hipcc keeps `uniform pointer + zext(offset)` as a 64-bit vector add per load otherwise).
@@ -456,15 +448,8 @@ __device__ __forceinline__ f32x4 read_frag(const float *lds, int row, int kbase)
 // cycles of MFMA.  (hipcc on its own sinks every read group next to its use: `ds_read; s_waitcnt lgkmcnt(0);
 // 4 x mfma`, which leaves the matrix pipe idle for the LDS round trip 16 times per k-tile.)  The
 // sched_group_barriers pin that order: the DS reads of the next slice, then the MFMAs of this one.
-#ifndef TCL_GEMM_EPI_AUX
-#define TCL_GEMM_EPI_AUX 2   // cache policy of the epilogues' buffer stores: 2 = non-temporal
-#endif
-#ifndef TCL_GEMM_SETPRIO
-#define TCL_GEMM_SETPRIO 2   // wave priority during the MFMA phase of gemm_f32_kernel (0 = leave it alone)
-#endif
-#ifndef TCL_GEMM_ABL
-#define TCL_GEMM_ABL 0   // timing ablations of side builds (wrong results): 1 no barriers, 2 no LDS stores, 4 no global loads in the loop, 8 no LDS reads
-#endif
+constexpr int kEpiAux = 2;     // cache policy of the epilogues' buffer stores: 2 = non-temporal (plain stores measured in DESIGN.md section 4)
+constexpr int kGemmPrio = 2;   // wave priority during the MFMA phase of gemm_f32_kernel
 // FIRST: the accumulators are undefined on entry; the first slice's MFMAs take an inline-constant zero as C (saves the 64
 // v_accvgpr_write of a zero fill: VALU instructions, which take issue slots from the MFMAs of the SIMD's other waves).
 template <int BM, int BN, int WM, int WN, int BKT, bool FIRST = false>
@@ -474,18 +459,18 @@ __device__ __forceinline__ void mma_ktile_kmajor(const float *As, const float *B
     float a_cur[TM], b_cur[TN], a_nxt[TM], b_nxt[TN];
     const float *ap = As + (lh * 4) * BM + (wid / WN) * 32 + lr, *bp = Bs + (lh * 4) * BN + (wid % WN) * 32 + lr;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a_cur[i] = (TCL_GEMM_ABL & 8) ? (float)(lr + i) : ap[i * (WM * 32)];
+    for (int i = 0; i < TM; ++i) a_cur[i] = ap[i * (WM * 32)];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b_cur[j] = (TCL_GEMM_ABL & 8) ? (float)(lh + j) : bp[j * (WN * 32)];
+    for (int j = 0; j < TN; ++j) b_cur[j] = bp[j * (WN * 32)];
     __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) / 2, 0);       // DS reads of slice 0
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) {
       if (sl + 1 < NSL) {
         const int kk = ((sl + 1) >> 2) * 8 + ((sl + 1) & 3);   // k row of the next slice (this lane half adds lh * 4)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a_nxt[i] = (TCL_GEMM_ABL & 8) ? a_cur[i] : ap[kk * BM + i * (WM * 32)];
+        for (int i = 0; i < TM; ++i) a_nxt[i] = ap[kk * BM + i * (WM * 32)];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b_nxt[j] = (TCL_GEMM_ABL & 8) ? b_cur[j] : bp[kk * BN + j * (WN * 32)];
+        for (int j = 0; j < TN; ++j) b_nxt[j] = bp[kk * BN + j * (WN * 32)];
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -503,73 +488,6 @@ __device__ __forceinline__ void mma_ktile_kmajor(const float *As, const float *B
         for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
       }
     }
-}
-
-// The same k-tile with INTERLEAVED fragments (TM = TN = 2, unpermuted [k][rows] images): MFMA block i of a wave owns the rows
-// wm0 + 2 l + i (l = the MFMA's 32 column index), block j the columns wn0 + 2 l + j, so one 8-byte read at a k serves both
-// blocks of an operand and ds_read2_b64 two consecutive k: 16 LDS reads per k-tile instead of 32.  Needs store_tile_il below.
-template <int BM, int BN, int WM, int WN, int BKT, bool FIRST = false>
-__device__ __forceinline__ void mma_ktile_kmajor_il(const float *As, const float *Bs, f32x16 (&acc)[2][2], int wid, int lr, int lh) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  constexpr int NP = BKT / 4;   // pairs of slices per k-tile
-  const float *ap = As + (lh * 4) * BM + (wid / WN) * (BM / WM) + 2 * lr, *bp = Bs + (lh * 4) * BN + (wid % WN) * (BN / WN) + 2 * lr;
-  f32x2 a_cur[2], b_cur[2], a_nxt[2], b_nxt[2];   // [k of the pair][block]
-#pragma unroll
-  for (int s = 0; s < 2; ++s) { a_cur[s] = *reinterpret_cast<const f32x2 *>(ap + s * BM); b_cur[s] = *reinterpret_cast<const f32x2 *>(bp + s * BN); }
-  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    if (p + 1 < NP) {
-      const int kk = ((p + 1) >> 1) * 8 + ((p + 1) & 1) * 2;   // first k row of the next pair (this lane half adds lh * 4)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) { a_nxt[s] = *reinterpret_cast<const f32x2 *>(ap + (kk + s) * BM); b_nxt[s] = *reinterpret_cast<const f32x2 *>(bp + (kk + s) * BN); }
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[s][j], a_cur[s][i], FIRST && p == 0 && s == 0 ? zero : acc[i][j], 0, 0, 0);
-        }
-    if (p + 1 < NP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS reads of pair p+1
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                   // MFMAs of pair p
-    if (p + 1 < NP) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) { a_cur[s] = a_nxt[s]; b_cur[s] = b_nxt[s]; }
-    }
-  }
-}
-
-// Epilogue of the interleaved accumulators of a 128 x 128 tile (2 x 2 waves): one pass per i; the (i, *) blocks of the four
-// waves = 64 staged rows (wave row, l) x 128 columns fill the 32 KB operand buffer exactly, float4 columns XOR-swizzled with
-// the row; they leave as whole 512-byte rows (buffer stores, loop-invariant offsets, the pass as a scalar offset).
-// Registers r, r + 1 (r even) of blocks (i, 0), (i, 1) = the four consecutive columns wn0 + 2 n_l .. + 3, n_l = (r & 3) +
-// 8 (r >> 2) + 4 lh; staged row (wave row w, l) = row w * 64 + 2 l + i of the tile.
-__device__ __forceinline__ void store_tile_il(f32x16 (&acc)[2][2], float *stg, const GemmArgs &g, unsigned z, int m0, int n0) {
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5, wm = wid >> 1, wn = wid & 1;
-  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(g.D + (int64_t)z * g.d_bs + (int64_t)m0 * g.d_ld + n0, 0, 0x7fffffff, 0x00020000);
-  const int d_ld4 = g.d_ld * 4;
-  const int rrow = tid >> 5, rc4 = tid & 31;   // readback: staged rows rrow + 8 k, float4 column rc4
-  const int voff = rrow * 2 * d_ld4 + rc4 * 16;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (i > 0) __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const f32x4 val = {acc[i][0][r], acc[i][1][r], acc[i][0][r + 1], acc[i][1][r + 1]};
-      const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      *reinterpret_cast<f32x4 *>(stg + (wm * 32 + lr) * 128 + ((wn * 64 + 2 * nl) ^ (lr << 2))) = val;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int l = 8 * (k & 3) + rrow;   // staged row rrow + 8 k = wave row (k >> 2), l
-      const f32x4 val = *reinterpret_cast<const f32x4 *>(stg + ((k >> 2) * 32 + l) * 128 + ((rc4 * 4) ^ (l << 2)));
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, voff, ((k >> 2) * 64 + 16 * (k & 3) + i) * d_ld4, TCL_GEMM_EPI_AUX /* 2 = nt */);
-    }
-  }
 }
 
 enum { EPI_STORE = 0, EPI_ARGMAX = 1 };
@@ -646,7 +564,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
   // The tiles were accumulated transposed (B fragment as the MFMA's A operand): a lane holds ONE row m of D and, in
   // each register quad, four consecutive columns n -> one 16-byte store per quad instead of four 4-byte stores.
   float *Db = g.D + (int64_t)z * g.d_bs;
-#ifndef TCL_GEMM_DIRECT_EPI   // A/B switch: the direct epilogue below for every case
   constexpr int ELD = WN * 32 + 4;   // staging row (floats), padded
   if (FULL && EPI == EPI_STORE && WM * 32 * ELD <= SMEM && g.d_vec) {
     // Full tiles: the accumulators go through LDS once so that every store instruction of a wave writes eight complete,
@@ -683,12 +600,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const f32x4 val = *reinterpret_cast<const f32x4 *>(smem + rd_off + k * (NT / (WN * 8)) * ELD);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, st_off[k], pass_off, TCL_GEMM_EPI_AUX /* 2 = nt */);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, st_off[k], pass_off, kEpiAux);
         }
       }
     return;
   }
-#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -752,14 +668,8 @@ __global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? ((BM 
   // FULL: operand cursors = a buffer descriptor on the block's (row0, k-tile 0) element + loop-invariant per-thread byte
   // offsets + a scalar byte offset that moves from k-tile to k-tile (segment change: rewind + a_ss / b_ss): no vector address
   // arithmetic per load.  (The launcher checks that these offsets fit 31 bits.)
-#ifdef TCL_GEMM_PTR_CURSORS   // A/B switch: the round-1 per-thread pointer cursors
-  constexpr bool BUF = false;
-#else
   constexpr bool BUF = FULL;
-#endif
-  const float *pa = FULL ? la.thread_base(Ab, g.a_ld, m0, tid) : nullptr;
-  const float *pb = FULL ? lb.thread_base(Bb, g.b_ld, n0, tid) : nullptr;
-  const int64_t a_st = la.step(g.a_ld), b_st = lb.step(g.b_ld), a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
+  const int64_t a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
   uint32_t a_off[la.NV], b_off[lb.NV];
   __amdgpu_buffer_rsrc_t ra, rb;
   int sa = 0, sb = 0;
@@ -771,37 +681,23 @@ __global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? ((BM 
   }
   int kt_next = 1;
   if (BUF) { la.load_buf(ra, a_off, 0); lb.load_buf(rb, b_off, 0); }
-  else if (FULL) { la.load_full(pa, a_st); lb.load_full(pb, b_st); }
   else {
     la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
     lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
   }
   constexpr bool PIPE = !A_KC && !B_KC;   // hand-pipelined fragment reads, permuted LDS rows
-#ifdef TCL_GEMM_FWD_IL   // A/B switch: interleaved fragments (half the LDS reads) for the full 128 x 128 store tiles
-  constexpr bool IL = PIPE && FULL && EPI == EPI_STORE && BM == 128 && BN == 128 && WM == 2 && WN == 2;
-#else
-  constexpr bool IL = false;
-#endif
   auto ktile = [&](auto firstc, int t) {
     constexpr bool FIRST = decltype(firstc)::value;
-    if (!(TCL_GEMM_ABL & 2) || t == 0) {
-      la.template store<PIPE && !IL ? WM : 0>(As, tid);
-      lb.template store<PIPE && !IL ? WN : 0>(Bs, tid);
-    }
-    if (!(TCL_GEMM_ABL & 1)) __syncthreads();
-    if (t + 1 < total && !(TCL_GEMM_ABL & 4)) {  // prefetch the next tile while this one is multiplied
+    la.template store<PIPE ? WM : 0>(As, tid);
+    lb.template store<PIPE ? WN : 0>(Bs, tid);
+    __syncthreads();
+    if (t + 1 < total) {  // prefetch the next tile while this one is multiplied
       if (BUF) {
         if (kt_next == ktiles) { kt_next = 0; sa += (int)(g.a_ss - (ktiles - 1) * a_k) * 4; sb += (int)(g.b_ss - (ktiles - 1) * b_k) * 4; }
         else { sa += (int)a_k * 4; sb += (int)b_k * 4; }
         ++kt_next;
         la.load_buf(ra, a_off, sa);
         lb.load_buf(rb, b_off, sb);
-      } else if (FULL) {
-        if (kt_next == ktiles) { kt_next = 0; pa += g.a_ss - (ktiles - 1) * a_k; pb += g.b_ss - (ktiles - 1) * b_k; }
-        else { pa += a_k; pb += b_k; }
-        ++kt_next;
-        la.load_full(pa, a_st);
-        lb.load_full(pb, b_st);
       } else {
         const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
         la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BK, g.M, g.K, tid);
@@ -810,11 +706,9 @@ __global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? ((BM 
     }
     // Raised wave priority while a wave multiplies (back to 0 for its staging): 1.3 % more cycles, but on the boxes that
     // throttle this kernel (2.22 GHz instead of 2.40) the clock only drops to 2.31-2.34 GHz: 1.06 -> 1.005 ms
-    // there, 0.943 -> 0.955 ms on an unthrottled box.  -DTCL_GEMM_SETPRIO=0 switches it off.
-    if (TCL_GEMM_SETPRIO > 0) __builtin_amdgcn_s_setprio(TCL_GEMM_SETPRIO);
-    if constexpr (IL) {
-      mma_ktile_kmajor_il<BM, BN, WM, WN, BK, FIRST>(As, Bs, acc, wid, lr, lh);
-    } else if (PIPE) {
+    // there, 0.943 -> 0.955 ms on an unthrottled box.
+    __builtin_amdgcn_s_setprio(kGemmPrio);
+    if (PIPE) {
       mma_ktile_kmajor<BM, BN, WM, WN, BK, FIRST>(As, Bs, acc, wid, lr, lh);
     } else
 #pragma unroll
@@ -835,108 +729,13 @@ __global__ void __launch_bounds__(WM *WN * 64, (EPI == EPI_STORE && FULL ? ((BM 
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], FIRST && kg == 0 && e == 0 ? zero : acc[i][j], 0, 0, 0);   // transposed tile, see the epilogues
           }
     }
-    if (TCL_GEMM_SETPRIO > 0) __builtin_amdgcn_s_setprio(0);
-    if (!(TCL_GEMM_ABL & 1)) __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
   };
   ktile(std::true_type{}, 0);   // peeled: its MFMAs start from an inline zero
   for (int t = 1; t < total; ++t) ktile(std::false_type{}, t);
 
-  if constexpr (IL) store_tile_il(acc, smem, g, z, m0, n0);
-  else gemm_epilogue<BM, BN, WM, WN, EPI, FULL, A_LDS + B_LDS>(acc, smem, g, z, m0, n0, tn);
-}
-
-// ---- forward contraction, LDS-DMA staging.  Full tiles only, both operands k-major (M % BM == N % BN == K % BKT == 0, 16-byte
-// aligned rows).  `global_load_lds_dwordx4` writes every k-tile straight into one of NST LDS stages: no staging registers, no
-// ds_write pass, tile t + NST - 1 in flight while tile t is multiplied, ONE barrier per k-tile.  One wave instruction lays
-// 64 x 16 bytes = 256 consecutive floats of the [k][rows] image; the row permutation of TileLoader::store<PW> is applied on the
-// per-lane SOURCE address (the LDS side of an LDS-DMA is lane-linear).
-typedef __attribute__((address_space(3))) void *lds_vptr;
-typedef const __attribute__((address_space(1))) void *glb_cvptr;
-
-template <int ROWS, int PW, int NW, int BKT>
-struct DmaTile {
-  static constexpr int PIECES = BKT * ROWS / 256, PER_WAVE = PIECES / NW, KPP = 256 / ROWS;   // k rows per piece
-  static_assert(256 % ROWS == 0 && PIECES % NW == 0, "a k-tile must split into whole 1 KiB pieces per wave");
-  // LDS-DMA through a buffer descriptor on the block's (row0, k-tile 0) element: this lane's byte offset of piece j = 0
-  // (loop-invariant register) + a scalar offset for the piece and the k-tile: `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`,
-  // no vector address arithmetic
-  __device__ __forceinline__ static uint32_t lane_offset(int64_t ld, int wid, int lane) {
-    const int f = lane * 4, k = wid * KPP + f / ROWS, pos = f % ROWS;
-    const int row = PW > 0 ? ((pos / 32) % PW) * (ROWS / PW) + (pos / (PW * 32)) * 32 + (pos & 31) : pos;
-    return (uint32_t)k * (uint32_t)ld * 4u + (uint32_t)row * 4u;
-  }
-  __device__ __forceinline__ static int jstep_bytes(int64_t ld) { return (int)((int64_t)NW * KPP * ld * 4); }
-  __device__ __forceinline__ static void issue(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, int soff, int js, float *stage, int wid) {
-#pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(stage + (j * NW + wid) * 256), 16, (int)voff, soff + j * js, 0, 0);
-  }
-};
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int BM, int BN, int WM, int WN, int BKT, int NST, int EPI>
-__global__ void __launch_bounds__(WM *WN * 64) gemm_f32_glds_kernel(GemmArgs g) {
-  constexpr int NW = WM * WN;
-  constexpr int STAGE = BKT * (BM + BN), SMEM = NST * STAGE;
-  __shared__ __attribute__((aligned(1024))) float smem[SMEM];
-  typedef DmaTile<BM, WM, NW, BKT> DA;
-  typedef DmaTile<BN, WN, NW, BKT> DB;
-  constexpr int PER_TILE = DA::PER_WAVE + DB::PER_WAVE;   // LDS-DMA instructions per wave and k-tile
-
-  const unsigned per_batch = g.tiles_m * g.tiles_n;
-  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned z = lin / per_batch, local = lin - z * per_batch;
-  constexpr unsigned GROUP = 8;
-  const unsigned gw = GROUP * g.tiles_n;
-  const unsigned gid = local / gw, first_m = gid * GROUP;
-  const unsigned gsz = min((unsigned)g.tiles_m - first_m, GROUP);
-  const unsigned tm = first_m + (local % gw) % gsz, tn = (local % gw) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int lr = lane & 31, lh = lane >> 5;
-
-  f32x16 acc[BM / WM / 32][BN / WN / 32];
-#pragma unroll
-  for (int i = 0; i < BM / WM / 32; ++i)
-#pragma unroll
-    for (int j = 0; j < BN / WN / 32; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A + (int64_t)(z / g.a_bdiv) * g.a_bs + m0), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.B + (int64_t)z * g.b_bs + n0), 0, 0x7fffffff, 0x00020000);
-  const uint32_t a_vo = DA::lane_offset(g.a_ld, wid, lane), b_vo = DB::lane_offset(g.b_ld, wid, lane);
-  const int a_js = DA::jstep_bytes(g.a_ld), b_js = DB::jstep_bytes(g.b_ld), a_k = (int)((int64_t)BKT * g.a_ld * 4), b_k = (int)((int64_t)BKT * g.b_ld * 4);
-  int sa = 0, sb = 0;
-  const int total = g.K / BKT;
-
-  // prologue: tiles 0 .. NST-2 in flight
-#pragma unroll
-  for (int st = 0; st < NST - 1; ++st)
-    if (st < total) {
-      DA::issue(ra, a_vo, sa, a_js, smem + st * STAGE, wid);
-      DB::issue(rb, b_vo, sb, b_js, smem + st * STAGE + BKT * BM, wid);
-      sa += a_k; sb += b_k;
-    }
-  int rd = 0, wr = NST - 1;
-  for (int t = 0; t < total; ++t) {
-    // tile t has landed once every wave's DMAs for it have retired (the NST - 2 younger tiles may stay in flight) ...
-    if (t + NST - 2 < total) wait_vmcnt<(NST - 2) * PER_TILE>(); else wait_vmcnt<0>();
-    // ... and every wave is past its reads of the stage that tile t + NST - 1 overwrites (multiplied in iteration t - 1)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + NST - 1 < total) {
-      DA::issue(ra, a_vo, sa, a_js, smem + wr * STAGE, wid);
-      DB::issue(rb, b_vo, sb, b_js, smem + wr * STAGE + BKT * BM, wid);
-      sa += a_k; sb += b_k;
-    }
-    mma_ktile_kmajor<BM, BN, WM, WN, BKT>(smem + rd * STAGE, smem + rd * STAGE + BKT * BM, acc, wid, lr, lh);
-    rd = rd + 1 == NST ? 0 : rd + 1;
-    wr = wr + 1 == NST ? 0 : wr + 1;
-  }
-  __syncthreads();
-  gemm_epilogue<BM, BN, WM, WN, EPI, true, SMEM>(acc, smem, g, z, m0, n0, tn);
+  gemm_epilogue<BM, BN, WM, WN, EPI, FULL, A_LDS + B_LDS>(acc, smem, g, z, m0, n0, tn);
 }
 
 // ---- wide contraction: 256 x 256 block tile, 4 waves, each wave 128 x 128 = 4 x 4 MFMA blocks (256 accumulators, in
@@ -948,32 +747,27 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_f32_glds_kernel(GemmArgs g) 
 //   * fragments of group g+1 are read during the 64 MFMAs of group g (two register sets);
 //   * the next tile's global loads (issued a whole k-tile earlier) are written to the other LDS stage during groups 0 and 1,
 //     and the loads of the tile after that are issued right behind them (one staging register set).
-// PERSIST (the forward contraction: K = C is short, the 256 KB output tile is not): one block per CU walks over output tiles
-// blockIdx.x, + gridDim.x, ...; the k-loop runs on across tile boundaries (the next output tile's first k-tiles are staged
-// during the last k-tiles of this one), the accumulators leave through an LDS region of their own, and their stores drain
-// under the next tile's MFMAs.
-// Full tiles only (M, N % 256 == 0, K % 32 == 0, 16-byte aligned rows).
-template <bool A_KC, bool B_KC, bool PERSIST>
+// Used for the two backward products (K = P is long).  A persistent variant for the forward contraction (one block per CU walking
+// over output tiles) was measured in round 2 and not adopted; it is no longer part of this file.
+// Full tiles only (M, N % 256 == 0, K % 64 == 0, 16-byte aligned rows).
+template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 2, NT = 256, TM = 4, TN = 4;
   constexpr int A_LDS = A_KC ? BM * KC_LD : BK * BM, B_LDS = B_KC ? BN * KC_LD : BK * BN, STAGE = A_LDS + B_LDS;
-  constexpr int EPI_LDS = WM * 32 * (WN * 32 + 4);   // staging of gemm_epilogue's whole-line path
   extern __shared__ __attribute__((aligned(16))) float smem_wide[];
   float *smem = smem_wide;
 
-  const unsigned per_batch = g.tiles_m * g.tiles_n, ntiles = per_batch * g.nbatch;
-  // output tiles of this block: first, first + stride, ... (count of them)
-  const unsigned first = PERSIST ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x), stride = PERSIST ? gridDim.x : 1;
-  const int count = PERSIST ? (int)((ntiles - first + stride - 1) / stride) : 1;
+  const unsigned per_batch = g.tiles_m * g.tiles_n;
+  const unsigned first = xcd_remap(blockIdx.x, gridDim.x);   // this block's output tile
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
   const int lr = lane & 31, lh = lane >> 5;
 
-  f32x16 acc[TM][TN];   // defined by the first k-tile of every output tile (mma_group<FIRST>: C = inline zero)
+  f32x16 acc[TM][TN];   // defined by the first k-tile (mma_group<FIRST>: C = inline zero)
 
   TileLoader<BM, NT, A_KC, true> la;
   TileLoader<BN, NT, B_KC, true> lb;
-  const int ktiles = g.K / BK, per_tile = ktiles * g.nseg, total = per_tile * count;
+  const int ktiles = g.K / BK, per_tile = ktiles * g.nseg, total = per_tile;
   // operand cursors: block-uniform origins of the k-tile to load next (scalar registers) + loop-invariant per-thread offsets
   uint32_t a_off[la.NV], b_off[lb.NV];
   la.thread_offsets(a_off, g.a_ld, tid);
@@ -990,17 +784,12 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
     sa = 0; sb = 0;
   };
   tile_cursors(first);
-  int kt = 0, in_tile = 0, issued = 0, tile_i = 0;   // the k-tile the cursors point at: within its segment / its output tile / overall
+  int kt = 0, issued = 0;   // the k-tile the cursors point at: within its segment / overall
   // moves the cursors to the next k-tile; past the last one they stay (the extra loads re-read it, nobody uses them)
   auto advance = [&]() {
-    if (PERSIST && in_tile + 1 == per_tile) {   // (rare, block-uniform) on to the next output tile
-      if (tile_i + 1 < count) { ++tile_i; ++issued; kt = 0; in_tile = 0; tile_cursors(first + tile_i * stride); }
-      return;
-    }
     // branch-free: a branch on the common path would split the MFMA stream of the k-loop into basic blocks
     const bool more = issued + 1 < total, wrap = kt + 1 == ktiles;
     issued += more ? 1 : 0;
-    in_tile += more ? 1 : 0;
     kt = more ? (wrap ? 0 : kt + 1) : kt;
     sa += more ? (wrap ? a_seg : a_k) : 0;
     sb += more ? (wrap ? b_seg : b_k) : 0;
@@ -1138,32 +927,18 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
         const f32x4 val = *reinterpret_cast<const f32x4 *>(stg + ((k >> 3) * 32 + l) * BN + ((rc4 * 4) ^ (l << 2)));
         const int voff = rrow * row_bytes + rc4 * 16;
         const int soff = (k >> 3) * (BM / WM) * d_ld4 + 4 * (k & 7) * row_bytes + (AQ ? i : i * 32) * d_ld4;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, voff, soff, TCL_GEMM_EPI_AUX /* 2 = nt */);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rd, voff, soff, kEpiAux);
       }
     }
   };
-  // two loops, so that the accumulators' way out is not part of the hot loop's register allocation: the inner one runs over
-  // the k-tiles of one output tile (an even number: the launcher checks), two per trip, the first from a zero C; the staging
-  // pipeline (cursors, LDS stages) runs on across output tiles
-  for (int tile_done = 0; tile_done < count; ++tile_done) {
-    ktile(S0{}, std::true_type{});
+  // the k-tiles of the output tile (an even number: the launcher checks), two per trip, the first from a zero C
+  ktile(S0{}, std::true_type{});
+  ktile(S1{}, NO{});
+  for (int kk = 2; kk < per_tile; kk += 2) {
+    ktile(S0{}, NO{});
     ktile(S1{}, NO{});
-    for (int kk = 2; kk < per_tile; kk += 2) {
-      ktile(S0{}, NO{});
-      ktile(S1{}, NO{});
-    }
-    if (PERSIST) {   // output tile complete: store it.  Stage 1 (the last k-tile's) is free: stage 0 already holds the next tile's first k-tile
-      const unsigned lin = first + tile_done * stride, z = lin / per_batch, local = lin - z * per_batch;
-      const int m0 = (int)(local % g.tiles_m) * BM, n0 = (int)(local / g.tiles_m) * BN;
-      if (AQ || BQ) {
-        store_tile_interleaved(smem + STAGE, z, m0, n0);
-        __syncthreads();   // read back by everyone before the next k-tile restages stage 1
-      } else {
-        gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, EPI_LDS>(acc, smem + 2 * STAGE, g, z, m0, n0, local / g.tiles_m);
-      }
-    }
   }
-  if (!PERSIST) {
+  {
     const unsigned z = first / per_batch, local = first - z * per_batch;
     const int m0 = (int)(local % g.tiles_m) * BM, n0 = (int)(local / g.tiles_m) * BN;
     __syncthreads();
@@ -1174,9 +949,9 @@ __global__ void __launch_bounds__(256) gemm_f32_wide_kernel(GemmArgs g) {
 
 // Once per device and instantiation: raise the kernel's dynamic-LDS limit to what it needs (139-147 KB of the CU's 160 KB) and
 // read the CU count.  Returns the CU count, or 0 if the device refuses (the caller then takes the 64 x 64-wave-tile kernels).
-template <bool A_KC, bool B_KC, bool PERSIST>
+template <bool A_KC, bool B_KC>
 static int wide_kernel_ready() {
-  constexpr size_t lds = (2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) + (PERSIST && A_KC && B_KC ? 64 * 68 : 0)) * sizeof(float);
+  constexpr size_t lds = 2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) * sizeof(float);
   static std::mutex mu;
   static int cus[64];   // 0 = not asked yet, -1 = refused
   int dev = 0;
@@ -1184,7 +959,7 @@ static int wide_kernel_ready() {
   std::lock_guard<std::mutex> lock(mu);
   if (cus[dev] == 0) {
     int n = 0;
-    const bool ok = hipFuncSetAttribute((const void *)gemm_f32_wide_kernel<A_KC, B_KC, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+    const bool ok = hipFuncSetAttribute((const void *)gemm_f32_wide_kernel<A_KC, B_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                     hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0;
     if (!ok) (void)hipGetLastError();   // a refusal is not an error of the call that asked
     cus[dev] = ok ? n : -1;
@@ -1192,15 +967,14 @@ static int wide_kernel_ready() {
   return cus[dev] > 0 ? cus[dev] : 0;
 }
 
-template <bool A_KC, bool B_KC, bool PERSIST>
-static int launch_gemm_wide(GemmArgs g, int cus, hipStream_t s, const char *what) {
+template <bool A_KC, bool B_KC>
+static int launch_gemm_wide(GemmArgs g, hipStream_t s, const char *what) {
   g.tiles_m = g.M / 256;
   g.tiles_n = g.N / 256;
   g.d_vec = aligned(g.D, 16) && g.d_ld % 4 == 0 && g.d_bs % 4 == 0;
-  int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
-  if (PERSIST && blocks > cus) blocks = cus;
-  constexpr size_t lds = (2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) + (PERSIST && A_KC && B_KC ? 64 * 68 : 0)) * sizeof(float);
-  hipLaunchKernelGGL((gemm_f32_wide_kernel<A_KC, B_KC, PERSIST>), dim3((unsigned)blocks), dim3(256), lds, s, g);
+  const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
+  constexpr size_t lds = 2 * ((A_KC ? 256 * KC_LD : BK * 256) + (B_KC ? 256 * KC_LD : BK * 256)) * sizeof(float);
+  hipLaunchKernelGGL((gemm_f32_wide_kernel<A_KC, B_KC>), dim3((unsigned)blocks), dim3(256), lds, s, g);
   return check_launch(what);
 }
 // the wide kernel wants whole 256 x 256 x 64 tiles, 16-byte aligned rows and enough tiles to give most CUs one
@@ -1215,13 +989,6 @@ static bool gemm_wide_ok(const GemmArgs &g, bool a_kc, bool b_kc) {
          (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(b_kc ? 256 : g.K) * g.b_ld * 4 < (1LL << 31) &&
          (int64_t)256 * g.d_ld * 4 < (1LL << 31) && (int64_t)(g.M / 256) * (g.N / 256) * g.nbatch >= 128;
 }
-
-#ifndef TCL_GLDS_BK
-#define TCL_GLDS_BK 32
-#endif
-#ifndef TCL_GLDS_NST
-#define TCL_GLDS_NST 2
-#endif
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI = EPI_STORE>
 static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
@@ -1238,17 +1005,7 @@ static int launch_gemm(GemmArgs g, hipStream_t s, const char *what) {
   const bool full = vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 &&
                     (int64_t)g.nseg * g.a_ss * 4 + (int64_t)(A_KC ? BM : g.K) * g.a_ld * 4 < (1LL << 31) &&
                     (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? BN : g.K) * g.b_ld * 4 < (1LL << 31) && (int64_t)BM * g.d_ld * 4 < (1LL << 31) && g.d_vec;
-#ifdef TCL_GEMM_GLDS   // A/B switch: LDS-DMA staging for the forward contraction (measured: no gain)
-  if constexpr (!A_KC && !B_KC) if (full && g.nseg == 1 && g.K % TCL_GLDS_BK == 0) {
-    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, WM, WN, TCL_GLDS_BK, TCL_GLDS_NST, EPI>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
-    return check_launch(what);
-  }
-#endif
-#ifdef TCL_GEMM_NO_FULL
-  if (false)
-#else
   if (full)
-#endif
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, true, EPI, true>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
   else if (vec)
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, A_KC, B_KC, true, EPI>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, g);
@@ -1315,17 +1072,9 @@ struct TileLoaderH {
     }
   }
 
-  // Full tiles (see TileLoader): per-thread cursor, block-uniform strides, no bounds checks
-  __device__ __forceinline__ static const float *thread_base(const float *base, int64_t ld, int row0, int tid) {
-    if (KC) return base + (int64_t)(row0 + tid / (BKH / 4)) * ld + (tid % (BKH / 4)) * 4;
-    return base + (int64_t)(tid / (ROWS / 4)) * ld + row0 + (tid % (ROWS / 4)) * 4;
-  }
+  // Full tiles (see TileLoader): block-uniform strides, no bounds checks
   __device__ __forceinline__ static int64_t step(int64_t ld) { return KC ? (NT / (BKH / 4)) * ld : (NT / (ROWS / 4)) * ld; }
   __device__ __forceinline__ static int64_t kstep(int64_t ld) { return KC ? BKH : BKH * ld; }
-  __device__ __forceinline__ void load_full(const float *p0, int64_t st) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const f32x4 *>(p0 + i * st);
-  }
   // The same loads as `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen`: a descriptor on the operand's (row0, k-tile 0)
   // element, loop-invariant per-thread 32-bit byte offsets, and the k-tile as a scalar byte offset: no vector address
   // arithmetic per load (hipcc keeps `uniform pointer + zext(offset)` as a 64-bit vector add per load otherwise).
@@ -1486,7 +1235,6 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
   // The tiles were accumulated transposed (B fragment as the MFMA's A operand): a lane holds ONE row m of D and, in
   // each register quad, four consecutive columns n -> one 16-byte store per quad instead of four 4-byte stores.
   float *Db = g.D + (int64_t)z * g.d_bs;
-#ifndef TCL_GEMM_DIRECT_EPI
   if (TM == 2 && TN == 2 && WM == 2 && WN == 2 && g.d_vec && m0 + BM <= g.M && n0 + BN <= g.N) {   // block-uniform
     // full tile: LDS-transposed epilogue with whole-line non-temporal stores, as in gemm_f32_kernel (this variant is bound by
     // the volume store)
@@ -1515,7 +1263,6 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
       }
     return;
   }
-#endif
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1800,7 +1547,6 @@ static int launch_gemm_bf16(GemmArgs g, int nsplit, hipStream_t s, const char *w
   TCL_REQUIRE(blocks > 0 && blocks < (1LL << 31), TCL_ERR_SHAPE, "%s: grid of %ld blocks", what, (long)blocks);
   const bool vec = gemm_vec_ok(g, A_KC, B_KC);
   const dim3 grd((unsigned)blocks), blk(WM * WN * 64);
-#ifndef TCL_GEMM_NO_FULL
   if (vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BKH == 0 && (int64_t)BM * g.d_ld * 4 < (1LL << 31) &&
       (int64_t)g.nseg * g.a_ss * 4 + (int64_t)(A_KC ? BM : g.K) * g.a_ld * 4 < (1LL << 31) &&
       (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? BN : g.K) * g.b_ld * 4 < (1LL << 31)) {   // full tiles (31-bit buffer offsets): cursor loads, no predication
@@ -1808,7 +1554,6 @@ static int launch_gemm_bf16(GemmArgs g, int nsplit, hipStream_t s, const char *w
     else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 1, true>), grd, blk, 0, s, g);
     return check_launch(what);
   }
-#endif
   if (nsplit == 2) {
     if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 2>), grd, blk, 0, s, g);
     else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, false, 2>), grd, blk, 0, s, g);
@@ -1977,11 +1722,7 @@ static bool norm_vec_ok(int64_t P, const void *a, const void *b, const void *c, 
   return P % 4 == 0 && aligned(a, 16) && aligned(b, 16) && aligned(c, 16) && aligned(d, 16) && aligned(e, 16);
 }
 static void launch_normalise(hipStream_t s, const float *x, const float *v, HatOut hat, float *nrm, int64_t BF, int C, int F, int64_t P) {
-#ifdef TCL_NORM_NO_KEEP   // A/B switch of side builds (-DTCL_NORM_NO_KEEP): the two-loop kernels everywhere
-  const bool keep = false;
-#else
   const bool keep = true;
-#endif
   const bool vec = norm_vec_ok(P, x, v, hat.f, nrm, nullptr) && aligned(hat.hi, 16) && aligned(hat.lo, 16);
 #define TCL_NORM_KEEP(NCG) hipLaunchKernelGGL((corr_normalise_keep_kernel<2, NCG, 16>), dim3((unsigned)cdiv(P, 128), (unsigned)BF), dim3(64 * NCG), 0, s, x, v, hat, nrm, C, F, (int)P)
   if (vec && keep && C <= 256) {   // single read of x: the thread's <= 16 channels stay in registers
@@ -1999,11 +1740,7 @@ static void launch_normalise(hipStream_t s, const float *x, const float *v, HatO
 }
 static void launch_normalise_bwd(hipStream_t s, const float *x, const float *v, const float *dhat, const float *nrm, float *gx, int64_t BF,
                                  int C, int F, int64_t P) {
-#ifdef TCL_NORM_NO_KEEP
-  const bool keep = false;
-#else
   const bool keep = true;
-#endif
   const bool vec = norm_vec_ok(P, x, v, dhat, nrm, gx);
 #define TCL_NORM_KEEP(NCG) hipLaunchKernelGGL((corr_normalise_bwd_keep_kernel<2, NCG, 16>), dim3((unsigned)cdiv(P, 128), (unsigned)BF), dim3(64 * NCG), 0, s, x, v, dhat, nrm, gx, C, F, (int)P)
   if (vec && keep && C <= 256) {   // x and d_hat read once; two pixels per lane so that 2 x 16 channels fit the register budget
@@ -2140,9 +1877,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_bs = F * C * P; g.b_bs = F * P * P; g.d_bs = C * P;
     g.a_ss = C * P; g.b_ss = P * P; g.a_bdiv = 1; g.nbatch = (int)B;
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, true>(g, nsplit, s, "tcl_corr4d_bwd(d_a bf16 gemm)");
-#ifndef TCL_GEMM_NO_WIDE
-    else if (gemm_wide_ok(g, true, true) && wide_kernel_ready<true, true, false>()) rc = launch_gemm_wide<true, true, false>(g, 0, s, "tcl_corr4d_bwd(d_a gemm)");
-#endif
+    else if (gemm_wide_ok(g, true, true) && wide_kernel_ready<true, true>()) rc = launch_gemm_wide<true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
     else rc = launch_gemm<256, 128, 4, 2, true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
     if (rc) return rc;
     launch_normalise_bwd(s, x_t, v_t, d_a, w.n_t, g_x_t, B, (int)C, 1, P);
@@ -2158,9 +1893,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_bs = C * P; g.b_bs = P * P; g.d_bs = C * P;
     g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
     if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, false>(g, nsplit, s, "tcl_corr4d_bwd(d_r bf16 gemm)");
-#ifndef TCL_GEMM_NO_WIDE
-    else if (gemm_wide_ok(g, true, false) && wide_kernel_ready<true, false, false>()) rc = launch_gemm_wide<true, false, false>(g, 0, s, "tcl_corr4d_bwd(d_r gemm)");
-#endif
+    else if (gemm_wide_ok(g, true, false) && wide_kernel_ready<true, false>()) rc = launch_gemm_wide<true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
     else rc = launch_gemm<256, 128, 4, 2, true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
     if (rc) return rc;
     launch_normalise_bwd(s, x_r, v_r, d_r, w.n_r, g_x_r, B * F, (int)C, (int)F, P);

@@ -266,11 +266,7 @@ static int ctx_xblocks(int64_t hw) { return (int)cdiv(hw, CTX_PXW * ctx_px(hw));
 // few loads in flight for HBM.  The pixel axis is therefore cut into `xs` ranges (grid.y) until about `want` waves exist, each
 // range keeping at least 4 steps of 64 * PX pixels.  A function of the shape only: the summation order stays deterministic.
 static int ctx_xsplit(int64_t waves, int64_t hw, int64_t want) {
-#ifdef TCL_CTX_XS   // A/B switch of side builds (-DTCL_CTX_XS=<n>): a fixed number of pixel ranges
-  const int forced = TCL_CTX_XS;
-#else
   const int forced = 0;
-#endif
   const int64_t nst = cdiv(hw, CTX_PXW * ctx_px(hw));
   int64_t xs = forced > 0 ? forced : cdiv(want, waves);
   if (xs > nst / 4) xs = nst / 4;

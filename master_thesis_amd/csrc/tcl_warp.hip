@@ -91,10 +91,6 @@ struct TapVals { F2U n, s; };
 template <bool W2>
 __device__ __forceinline__ TapVals fetch_taps(const float *plane, const Taps &t, int W) {
   TapVals v;
-#ifdef TCL_ABL_NOLOAD   // diagnostic side build: no gathers (values from the address bits)
-  v.n.a = __int_as_float(t.ya); v.n.b = __int_as_float(t.xa); v.s.a = __int_as_float(t.yb); v.s.b = 1.f;
-  return v;
-#endif
   if (W2) {
     // unsigned 32-bit offsets off the (wave-uniform) plane pointer: one scalar base + vector offset per load, no 64-bit VALU
     v.n = *reinterpret_cast<const F2U *>(plane + (unsigned)(t.ya * W + t.xa));
@@ -164,10 +160,7 @@ constexpr int FWD_MAXC = 3;             // channels whose taps are fetched toget
 // lane, ~90 vector instructions) two chunks per workgroup are 7 % faster than one (0.0664 vs 0.0718 ms: the waves are so short
 // that their launch shows), four and eight are not; with theta (240 vector instructions per pixel) two / four / eight are
 // 13-20 % SLOWER (the iterations of a wave do not overlap, and the kernel is bound by vector issue, not by dispatch).
-#ifndef TCL_WARP_FWD_ITERS_GRID
-#define TCL_WARP_FWD_ITERS_GRID 2
-#endif
-template <bool HAS_THETA> struct FwdIters { static constexpr int value = HAS_THETA ? 1 : TCL_WARP_FWD_ITERS_GRID; };
+template <bool HAS_THETA> struct FwdIters { static constexpr int value = HAS_THETA ? 1 : 2; };
 
 template <bool HAS_THETA, bool W2, int VMODE, bool C3, bool VMAP>
 __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chunk);
@@ -249,7 +242,6 @@ __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chun
   // Measured (round 3, cache-cold legs, A/B in the same runs): align_set (grid source, nearest visibility) 65.8 -> 63.9 us with
   // the shared taps; the affine forward (theta source, bilinear visibility: 8 west + 8 masked east loads instead of 8 gathers)
   // 0.261 -> 0.308 ms, i.e. that kernel pays per vector-memory INSTRUCTION, not per byte the L1 returns.  So: grid sources only.
-#ifndef TCL_WARP_FWD_NO_SHARE
   if (C3 && !HAS_THETA) {
     // ---- west taps of every plane (unconditional), then the east taps of the lanes that cannot take them from lane + 1
     constexpr bool VB = VMODE == TCL_VMODE_BILINEAR_THRESHOLD;
@@ -289,7 +281,6 @@ __device__ __forceinline__ void warp_fwd_body(const WarpArgs &a, int n, int chun
     }
     return;
   }
-#endif
   if (!ok) return;
   // ---- loads
   float vnear = 0.f;
@@ -362,12 +353,8 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
   const int H = a.H, W = a.W, HW = H * W, nchunk = (HW + 255) >> 8;
   // the forward's (XCD, chunk, image / 8) order: one XCD walks one image, so the source rows that neighbouring chunks share are
   // fetched into ONE L2 (round 2 measured 1.28x the algorithmic bytes with the (chunk, image) grid, at the same speed)
-#ifdef TCL_WARP_BWD_NO_XCD   // A/B switch: the round-2 grid
-  const int n = blockIdx.y, chunk = blockIdx.x;
-#else
   int n, chunk;
   if (!warp_block(nchunk, 1, a.NB * a.NF, n, chunk)) return;
-#endif
   const int b = (int)a.fd_nf.div((unsigned)n), f = n - b * a.NF;
   const int pix0 = chunk * 256 + threadIdx.x;
   const bool ok = pix0 < HW;
@@ -563,12 +550,8 @@ template <bool HAS_THETA, bool HAS_GX, bool C3>
 __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int tiles_x, int tiles_y) {
   __shared__ float red[4][6];
   const int H = a.H, W = a.W, HW = H * W;
-#ifdef TCL_WARP_BWD_NO_XCD
-  const int n = blockIdx.y, tile = blockIdx.x;
-#else
   int n, tile;   // (XCD, tile, image / 8): an image's tiles, which share source rows and columns, stay on one XCD's L2
   if (!warp_block(tiles_x * tiles_y, 1, a.NB * a.NF, n, tile)) return;
-#endif
   const int trow = tile / tiles_x;
   const int lx = threadIdx.x & 63, ly = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ty0 = trow * TILE_H + ly * TILE_K, tx0 = (tile - trow * tiles_x) * TILE_W;   // this wave's strip: rows ty0 .. ty0 + TILE_K - 1
@@ -827,11 +810,7 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
                 g_grid, partial, (int)NB, (int)NF, (int)C, (int)H, (int)W, align_corners, lin_step(W), lin_step(H),
                 make_fastdiv((uint32_t)W), make_fastdiv((uint32_t)NF)};
   hipStream_t s = (hipStream_t)stream;
-#ifdef TCL_WARP_BWD_NO_XCD
-  const dim3 grd((unsigned)per, (unsigned)N), blk(256);
-#else
   const dim3 grd = warp_grid(per, 1, N), blk(256);
-#endif
 #define TCL_LAUNCH_WBWD(TH, GX)                                                                   \
   do {                                                                                             \
     if (W >= 2 && C == 3) hipLaunchKernelGGL((warp_bwd_kernel<TH, GX, true, true>), grd, blk, 0, s, a);   \
@@ -840,20 +819,12 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
   } while (0)
   // images of at least one tile: the tiled kernel for the input gradient (LDS-staged scatter-add) and for the theta gradient
   // (one set of block sums per 2048 pixels); the grid-gradient-only case stays on the one-pixel-per-lane kernel
-#ifdef TCL_BWD_GRID_TILED   // A/B: the grid-gradient-only case on the tiled kernel too
-  const bool tiled = W >= TILE_W && H >= TILE_H && W < 16384 && H < 16384;
-#else
   const bool tiled = W >= TILE_W && H >= TILE_H && W < 16384 && H < 16384 && (g_x || theta);
-#endif
   int nblk = per;
   if (tiled) {
     const int tx = (int)cdiv(W, TILE_W), ty = (int)cdiv(H, TILE_H);
     nblk = tx * ty;   // <= cdiv(H * W, 256) for H >= 32, W >= 64: the theta workspace is large enough
-#ifdef TCL_WARP_BWD_NO_XCD
-    const dim3 tg((unsigned)nblk, (unsigned)N);
-#else
     const dim3 tg = warp_grid(nblk, 1, N);
-#endif
 #define TCL_LAUNCH_WTILE(TH, GX)                                                                          \
   do {                                                                                                     \
     if (C == 3) hipLaunchKernelGGL((warp_bwd_tile_kernel<TH, GX, true>), tg, blk, 0, s, a, tx, ty);        \

@@ -158,6 +158,11 @@ class CPNOriginal(nn.Module):
         f_r = self.A_Encoder(x_refs.transpose(1, 2).reshape(-1, c, h, w), m_refs.transpose(1, 2).reshape(-1, 1, h, w))
         f_t = f_t.unsqueeze(1).expand(b, ref_n, *f_t.shape[1:]).reshape(b * ref_n, *f_t.shape[1:])
         theta_rt = self.A_Regressor(f_t, f_r)   # target features first, as the reference has it
+        if not torch.is_grad_enabled() and c == 3 and w >= 2:
+            # inference (thesis_cpn/runner.py runs this under no_grad): frames, visibility (hole masks flipped per tap) and
+            # v_maps (models/cpn_original.py:287) leave ONE launch
+            return _ops.warp_infer(x_refs, m_refs, m_target, theta=theta_rt.float(), align_corners=False,
+                                   v_mode=_lib.VMODE_BILINEAR_THRESHOLD)
         x_aligned, v_aligned, _ = _cpn.affine_align(x_refs, m_refs, None, theta_rt.float(), list(range(ref_n)))
         return x_aligned, v_aligned, _ops.vmap(v_aligned, 1 - m_target)
 
