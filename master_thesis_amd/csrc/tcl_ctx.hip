@@ -601,7 +601,13 @@ __global__ void __launch_bounds__(256) ctx_bwd_dmatch_kernel(const float *g_p_in
                                                              int variant, int xblocks, int csplit) {
   constexpr int NPX = CTX_PXW * PX;
   __shared__ float red[4][RU][NPX];
-  const int b = blockIdx.y, bxi = blockIdx.x % xblocks, cs = blockIdx.x / xblocks;
+  // grid (8 = XCD, x-chunk and channel split, batch item / 8): workgroups are dealt round-robin over the XCDs in linear order, so
+  // blockIdx.x IS the XCD and all chunks of one batch item run on one XCD.  A 512-byte chunk of a 6,360-byte plane row starts at
+  // no line boundary; with the (chunk, item) grid of round 2 neighbouring chunks sat on different XCDs and each fetched the
+  // shared boundary line into its own L2: 1.36x the algorithmic bytes (TCC fetch counters), now one L2 serves both.
+  const int b = blockIdx.z * kNumXCD + blockIdx.x;
+  if (b >= B) return;   // block-uniform (padding blocks of the last group)
+  const int bxi = blockIdx.y % xblocks, cs = blockIdx.y / xblocks;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int x0 = (bxi * CTX_PXW + lane) * PX;
   const bool ok = x0 < hw;
@@ -1102,7 +1108,8 @@ extern "C" int tcl_ctx_bwd(const float *g_p_in, const float *g_c_mask, const flo
   float *coef = (float *)((char *)workspace + round_up((size_t)B * R * cdiv(hw, 64) * 4, 256));
   float *dpart = (float *)((char *)coef + round_up((size_t)B * R * 4, 256));
   const int csplit = ctx_bwd_csplit(B, C, hw), xb = ctx_xblocks(hw), px = ctx_px(hw), ru = ctx_bwd_ru(R);
-  const dim3 grd((unsigned)(xb * csplit), (unsigned)B), blk(256);
+  TCL_REQUIRE(xb * csplit < 65536, TCL_ERR_SHAPE, "tcl_ctx_bwd: feature map too large (%d pixels)", hw);
+  const dim3 grd(kNumXCD, (unsigned)(xb * csplit), (unsigned)cdiv(B, kNumXCD)), blk(256);
 #define TCL_CTX_DM(RU, PX) hipLaunchKernelGGL((ctx_bwd_dmatch_kernel<RU, PX>), grd, blk, 0, s, g_p_in, c_feats, dpart, (int)B, (int)C, (int)R, hw, variant, xb, csplit)
 #define TCL_CTX_DM_PX(RU)                \
   do {                                   \
