@@ -456,7 +456,12 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(WarpBwdArgs a) {
 //     addresses.  What leaves is ~(1 + 1/TILE_K) adds per source pixel and channel in 64-byte aligned requests.  Any flow is
 //     handled: where the merges do not apply the adds simply go out unmerged.
 //   * the theta gradient: six block sums per 2048 pixels instead of per 256 (the reductions, not HBM, bound the small kernel).
-constexpr int TILE_W = 64, TILE_K = 8, TILE_H = 4 * TILE_K;
+// The block's four waves: TILE_WX side by side x TILE_WY stacked.  Measured (round 3, cold legs): four side by side (8 rows x 256
+// columns per block: 1 KB contiguous per plane row instead of 256 B) change nothing for the scatter-add (0.160 vs 0.163 ms) and
+// cost the theta gradient 7 % at W = 424 (idle lanes in the second tile of a row): the stacked arrangement stays.
+constexpr int TILE_WX = 1, TILE_WY = 4 / TILE_WX;
+constexpr int TILE_K = 8, TILE_BW = 64 * TILE_WX, TILE_BH = TILE_K * TILE_WY;   // block tile in pixels
+constexpr int TILE_MIN_W = 64, TILE_MIN_H = 32;                                  // smaller images stay on the one-pixel-per-lane kernel
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -554,7 +559,8 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
   if (!warp_block(tiles_x * tiles_y, 1, a.NB * a.NF, n, tile)) return;
   const int trow = tile / tiles_x;
   const int lx = threadIdx.x & 63, ly = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ty0 = trow * TILE_H + ly * TILE_K, tx0 = (tile - trow * tiles_x) * TILE_W;   // this wave's strip: rows ty0 .. ty0 + TILE_K - 1
+  const int wy = ly / TILE_WX, wx = ly - wy * TILE_WX;
+  const int ty0 = trow * TILE_BH + wy * TILE_K, tx0 = (tile - trow * tiles_x) * TILE_BW + wx * 64;   // this wave's strip: rows ty0 .. ty0 + TILE_K - 1
   const int b = (int)a.fd_nf.div((unsigned)n), f = n - b * a.NF;
   const bool ac = a.align_corners != 0;
   const float mx = ac ? 0.5f * (float)(W - 1) : 0.5f * (float)W;
@@ -569,12 +575,12 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
   // theta source: the base-grid coordinate of the column (two IEEE divisions for align_corners = False) and theta[0] * xs once
   // per lane, the row's coordinate and theta[1] * ys once per block (LDS table, read as a broadcast).  The products enter the
   // same additions in the same order as in sample_pos: bit-identical positions.
-  __shared__ float4 ytab[HAS_THETA ? TILE_H : 1];
+  __shared__ float4 ytab[HAS_THETA ? TILE_BH : 1];
   float xs_l = 0.f, ax = 0.f, dx = 0.f, th2 = 0.f, th5 = 0.f;
   if (HAS_THETA) {
     const float *th = a.theta + (int64_t)n * 6;
-    if (threadIdx.x < TILE_H) {
-      const float ysr = base_coord_step(min(trow * TILE_H + (int)threadIdx.x, H - 1), H, a.stepy, ac);
+    if (threadIdx.x < TILE_BH) {
+      const float ysr = base_coord_step(min(trow * TILE_BH + (int)threadIdx.x, H - 1), H, a.stepy, ac);
       ytab[threadIdx.x] = make_float4(__fmul_rn(th[1], ysr), __fmul_rn(th[4], ysr), ysr, 0.f);
     }
     xs_l = base_coord_step(x, W, a.stepx, ac);
@@ -599,7 +605,7 @@ __global__ void __launch_bounds__(256) warp_bwd_tile_kernel(WarpBwdArgs a, int t
       r.pix = y * W + x;
       float ix, iy;
       if (HAS_THETA) {
-        const float4 yt = ytab[min(ly * TILE_K + k, TILE_H - 1)];
+        const float4 yt = ytab[min(wy * TILE_K + k, TILE_BH - 1)];
         r.xs = xs_l; r.ys = yt.z;
         ix = unnormalise(__fadd_rn(__fadd_rn(ax, yt.x), th2), W, ac);
         iy = unnormalise(__fadd_rn(__fadd_rn(dx, yt.y), th5), H, ac);
@@ -780,7 +786,9 @@ extern "C" int tcl_affine_grid(const float *theta, float *grid, int64_t N, int64
 
 extern "C" size_t tcl_warp_bwd_workspace_bytes(int64_t NB, int64_t NF, int64_t H, int64_t W, int have_theta) {
   if (!have_theta || NB <= 0 || NF <= 0 || H <= 0 || W <= 0) return 0;
-  return round_up((size_t)(NB * NF) * cdiv(H * W, 256) * 6 * sizeof(float), 256);
+  // six partial sums per block and image: the larger of the two kernels' block counts (256-pixel chunks / tiles of TILE_BW x TILE_BH)
+  const int64_t nblk = cdiv(H * W, 256) > cdiv(W, TILE_BW) * cdiv(H, TILE_BH) ? cdiv(H * W, 256) : cdiv(W, TILE_BW) * cdiv(H, TILE_BH);
+  return round_up((size_t)(NB * NF) * nblk * 6 * sizeof(float), 256);
 }
 
 extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_sf, int64_t go_sc, const float *x,
@@ -819,11 +827,11 @@ extern "C" int tcl_warp_bwd(const float *grad_x_out, int64_t go_sb, int64_t go_s
   } while (0)
   // images of at least one tile: the tiled kernel for the input gradient (LDS-staged scatter-add) and for the theta gradient
   // (one set of block sums per 2048 pixels); the grid-gradient-only case stays on the one-pixel-per-lane kernel
-  const bool tiled = W >= TILE_W && H >= TILE_H && W < 16384 && H < 16384 && (g_x || theta);
+  const bool tiled = W >= TILE_MIN_W && H >= TILE_MIN_H && W < 16384 && H < 16384 && (g_x || theta);
   int nblk = per;
   if (tiled) {
-    const int tx = (int)cdiv(W, TILE_W), ty = (int)cdiv(H, TILE_H);
-    nblk = tx * ty;   // <= cdiv(H * W, 256) for H >= 32, W >= 64: the theta workspace is large enough
+    const int tx = (int)cdiv(W, TILE_BW), ty = (int)cdiv(H, TILE_BH);
+    nblk = tx * ty;   // tcl_warp_bwd_workspace_bytes sizes the theta workspace for the larger block count
     const dim3 tg = warp_grid(nblk, 1, N);
 #define TCL_LAUNCH_WTILE(TH, GX)                                                                          \
   do {                                                                                                     \
