@@ -1338,7 +1338,7 @@ struct Bf16Ops { const __bf16 *a_hi, *a_lo, *b_hi, *b_lo; };
 // D = k-tiles in flight in registers beyond the staged one (the loop is unrolled D times, ktiles % D == 0): with one tile a wave
 // had 4 x 16 bytes per lane on their way from L2 for ~0.3 us of MFMA work per k-tile, less than the loaded L2 latency.
 template <int BM, int BN, int WM, int WN, int NS, int EPI, bool FULL, int D>
-__global__ void __launch_bounds__(WM *WN * 64, (NS == 1 && (BM / WM) * (BN / WN) <= 64 * 64) ? 3 : 2) gemm_bf16op_kernel(GemmArgs g, Bf16Ops o) {
+__global__ void __launch_bounds__(WM *WN * 64, (BM / WM) * (BN / WN) > 128 * 64 ? 1 : ((NS == 1 && (BM / WM) * (BN / WN) <= 64 * 64) ? 3 : 2)) gemm_bf16op_kernel(GemmArgs g, Bf16Ops o) {
   constexpr int NT = WM * WN * 64, BKT = 32;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_IMG = BKT * McLd<BM>::value, B_IMG = BKT * McLd<BN>::value, STAGE = NS * (A_IMG + B_IMG);
@@ -1359,13 +1359,7 @@ __global__ void __launch_bounds__(WM *WN * 64, (NS == 1 && (BM / WM) * (BN / WN)
   const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
 
   const int64_t a_base = (int64_t)(z / g.a_bdiv) * g.a_bs, b_base = (int64_t)z * g.b_bs;
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc[TM][TN];   // defined by the first MFMA group (C = inline zero: no zero fill, 64 vector instructions less per wave)
 
   TileLoaderB<BM, NT, BKT> la[D][NS];
   TileLoaderB<BN, NT, BKT> lb[D][NS];
@@ -1417,16 +1411,18 @@ __global__ void __launch_bounds__(WM *WN * 64, (NS == 1 && (BM / WM) * (BN / WN)
       if (NS == 2) f.bl[j] = read_frag_h<BN, false>(Bl, wn0 + j * 32, ks, lane);
     }
   };
-  auto mma = [&](const Frags &f) {
+  auto mma = [&](const Frags &f, auto firstc) {
+    constexpr bool FIRST = decltype(firstc)::value;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if (NS == 2) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);   // transposed tiles, see gemm_epilogue
+        if (NS == 2) {   // the small cross terms first, hi * hi last (as before: only the first C operand changes)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[j], f.al[i], FIRST ? zero : acc[i][j], 0, 0, 0);   // transposed tiles, see gemm_epilogue
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[j], f.ah[i], (FIRST && NS == 1) ? zero : acc[i][j], 0, 0, 0);
       }
   };
   Frags f0, f1;
@@ -1444,14 +1440,14 @@ __global__ void __launch_bounds__(WM *WN * 64, (NS == 1 && (BM / WM) * (BN / WN)
   // The body is straight-line (no branch: hipcc's waits then COUNT the outstanding LDS / memory operations instead of draining
   // them at a join).  Past the last tile the staging simply runs on: the loads re-read the last tile, the other stage receives
   // a copy nobody multiplies.
-  auto ktile = [&](auto uc, int t) {   // k-tile t + U of an unrolled trip (t % D == 0)
+  auto ktile = [&](auto uc, int t, auto firstc) {   // k-tile t + U of an unrolled trip (t % D == 0); firstc: the kernel's first trip
     constexpr int U = decltype(uc)::value;
     if (U >= D) return;
     const int st = D % 2 == 0 ? (U & 1) : ((t + U) & 1);
     using NEXT = std::integral_constant<int, (U + 1) % D>;   // the set that holds tile t + U + 1
     read_frags(f1, st, 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma(f0);                             // queued BEFORE the wave may have to wait for the next tile's global loads
+    mma(f0, std::integral_constant<bool, decltype(firstc)::value && U == 0>{});   // queued BEFORE the wave may have to wait for the next tile's global loads
     __builtin_amdgcn_sched_barrier(0);
     stage(NEXT{}, 1 - st);               // everyone left that stage before the barrier of the previous k-tile
     fetch(NEXT{}, min(t + U + 1 + D, ktiles - 1));
@@ -1459,23 +1455,29 @@ __global__ void __launch_bounds__(WM *WN * 64, (NS == 1 && (BM / WM) * (BN / WN)
     __syncthreads();                     // all waves: group-1 fragments of this tile in registers, the next tile staged
     read_frags(f0, 1 - st, 0);
     __builtin_amdgcn_sched_barrier(0);
-    mma(f1);
+    mma(f1, std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
   };
+  auto trip = [&](auto firstc, int t) {
+    ktile(std::integral_constant<int, 0>{}, t, firstc); ktile(std::integral_constant<int, 1>{}, t, firstc);
+    ktile(std::integral_constant<int, 2>{}, t, firstc); ktile(std::integral_constant<int, 3>{}, t, firstc);
+  };
+  trip(std::true_type{}, 0);   // peeled: its first MFMAs define the accumulators
 #pragma unroll 1
-  for (int t = 0; t < ktiles; t += D) {
-    ktile(std::integral_constant<int, 0>{}, t); ktile(std::integral_constant<int, 1>{}, t);
-    ktile(std::integral_constant<int, 2>{}, t); ktile(std::integral_constant<int, 3>{}, t);
-  }
+  for (int t = D; t < ktiles; t += D) trip(std::false_type{}, t);
   __syncthreads();
   gemm_epilogue<BM, BN, WM, WN, EPI, FULL, SMEM_F>(acc, reinterpret_cast<float *>(smem), g, z, m0, n0, tn);
 }
 
-// Measured at C2 (round 3): 128 x 128 tiles with two k-tiles in flight.  256 x 128 tiles (4 waves of 128 x 64, or 8 of 64 x 64):
-// store variant 0.258 / 0.287 ms against 0.224, fused argmax 0.228 / 0.241 against 0.225; one or four k-tiles in flight:
-// 0.215 / 0.246 ms against 0.222.  The matrix pipe is busy 0.40 of the kernel's cycles in all of them (SQ_VALU_MFMA_BUSY_CYCLES,
-// 2.1 GHz under this load): at K = 256 a tile's 64 MFMAs per wave stand against ~420 vector instructions per wave (zero fill,
-// addresses, the argmax scan / the LDS-transposed store), which take issue slots from the SIMD's other waves.
+// Measured at C2 (round 3, profiles/r3_bf16_kloop_ablations.txt): 128 x 128 tiles with two k-tiles in flight.  256 x 128 tiles
+// (4 waves of 128 x 64, or 8 of 64 x 64): store variant 0.258 / 0.287 ms against 0.224, fused argmax 0.228 / 0.241 against 0.225;
+// 256 x 256 tiles (4 waves of 128 x 128, one wave per SIMD, this same two-group pipeline): fused argmax kernel 223 us against 157;
+// one or four k-tiles in flight: 0.215 / 0.246 ms against 0.222.  The matrix pipe is busy 0.40 of the kernel's cycles
+// (SQ_VALU_MFMA_BUSY_CYCLES; 2.1 GHz under this load).  Where the k-loop's 157 us go (side builds without parts of the loop, no
+// epilogue: the epilogues are hidden under other blocks' loops): fragment reads + MFMAs alone 98 us (a 64 x 64 wave tile needs as
+// many LDS-array cycles for its transposing reads as matrix-pipe cycles for its MFMAs), the ds_write_b128 staging +41 us (13
+// cycles of VGPR -> LDS transfer per wave instruction, which the MFMAs do not overlap), the global loads and their waits +18 us,
+// the barrier nothing.  K = 1024 instead of 256 takes 4.0x as long: steady state, not per-tile start-up.
 constexpr int BF16_D = 2;
 #define TCL_BF16_TILE 128, 128, 2, 2
 // dynamic LDS above 64 KB needs the kernel attribute raised once per device (cached under a mutex, like wide_kernel_ready)
