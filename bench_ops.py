@@ -166,8 +166,11 @@ def bench_argmax(iters):
     g = torch.Generator().manual_seed(4)
     xt = torch.randn(B, C, S, S, generator=g).to(DEV)
     xr = torch.randn(B, C, F, S, S, generator=g).to(DEV)
-    ms = timed(lambda: _ops.corr4d_argmax_flow(xt, None, xr, None), iters)
-    report("corr4d + corr_to_flow fused 64x64 C=256 x16 pairs", ms, flops=2.0 * 4096 * 4096 * C * B * F, units=B * F)
+    from master_thesis_amd import _lib
+    for name, prec in (("f32", _lib.PREC_F32), ("bf16x3", _lib.PREC_BF16X3), ("bf16", _lib.PREC_BF16)):
+        ms = timed(lambda: _ops.corr4d_argmax_flow(xt, None, xr, None, precision=prec), iters)
+        report("corr4d + corr_to_flow fused 64x64 C=256 x16 pairs (%s)" % name, ms, flops=2.0 * 4096 * 4096 * C * B * F, units=B * F,
+               note="algorithmic flops; the fp32 figure is against 157.3 TF, the bf16 ones run on the 2.5 PF pipe (bf16x3 issues 3x the flops)")
 
 
 def bench_movement(iters):
