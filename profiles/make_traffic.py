@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the raw PMC passes (r2_legs_hbm_bytes_raw.json; round 1: r1_c2_hbm_bytes_raw.json, r1_ops_hbm_bytes_raw.json).
+"""profiles/traffic.json from the raw PMC passes (round 3: r3_legs_hbm_bytes_raw.json; round 2: r2_legs_hbm_bytes_raw.json; round 1:
+r1_c2_hbm_bytes_raw.json, r1_ops_hbm_bytes_raw.json).
 
 The raw files are what `profiles/microbench/pmc_bytes.sh` writes: per kernel, the average FETCH_SIZE and WRITE_SIZE (KiB) of two separate
-`rocprofv3 --pmc` passes over `bench.py --legs-only corr,warp,c4` (round 2: the cache-cold, rotating-buffer launches of every leg;
+`rocprofv3 --pmc` passes over `bench.py --legs-only corr,warp,c4` (rounds 2 and 3: the cache-cold, rotating-buffer launches of every leg;
 round 1 used `bench.py --steps 1 ...` and `bench_ops.py --iters 2`).  hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE is doubled as
 MI355X_MICROARCH.md prescribes for gfx950 (a 128-byte request is counted as 64 bytes; calibrated there for 16-byte-per-lane
 streaming loads, so for the 4- and 8-byte-per-lane loads of the streaming kernels it is an upper estimate).
@@ -18,30 +19,29 @@ HAT = 256 * 4096 * 4                           # one normalised operand of one p
 NPIX_C3, NPIX_C4 = 128 * 256 * 256, 320 * 240 * 424
 CF = 32 * 128 * 11 * 30 * 53 * 4               # c_feats at C4
 ROWS = [  # (label, raw file, kernel-name substring, algorithmic bytes per launch)
-    ("gemm_f32_fwd (C2, 16 pairs)", "legs", "gemm_f32_kernel<128, 128, 2, 2, false, false", 16 * (C2_PAIR + 2 * HAT)),
-    ("gemm_bf16x3_fwd (C2)", "legs", "gemm_bf16_kernel<128, 128, 2, 2, false, false, true, 2", 16 * (C2_PAIR + 2 * HAT)),
-    ("gemm_bf16_fwd (C2)", "legs", "gemm_bf16_kernel<128, 128, 2, 2, false, false, true, 1", 16 * (C2_PAIR + 2 * HAT)),
-    ("gemm_f32_wide bwd_d_a (C2)", "legs", "gemm_f32_wide_kernel<true, true, false>", 16 * (C2_PAIR + 2 * HAT)),
-    ("gemm_f32_wide bwd_d_r (C2)", "legs", "gemm_f32_wide_kernel<true, false, false>", 16 * (C2_PAIR + 2 * HAT)),
-    ("gemm_f32 256x128 bwd_d_a (C2; fallback since the wide kernel)", "legs", "gemm_f32_kernel<256, 128, 4, 2, true, true", 16 * (C2_PAIR + 2 * HAT)),
-    ("gemm_f32 256x128 bwd_d_r (C2; fallback since the wide kernel)", "legs", "gemm_f32_kernel<256, 128, 4, 2, true, false", 16 * (C2_PAIR + 2 * HAT)),
-    ("corr_normalise (one of two launches)", "legs", "corr_normalise_keep_kernel", 16 * 2 * HAT),
+    ("gemm_f32_fwd (C2, 16 pairs)", "legs", "gemm_f32_kernel<128, 128, 2, 2, false, false, true, 0", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_bf16x3_fwd (C2; bf16 hi + lo operand images)", "legs", "gemm_bf16op_kernel<128, 128, 2, 2, 2, 0", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_bf16_fwd (C2; bf16 operand images)", "legs", "gemm_bf16op_kernel<128, 128, 2, 2, 1, 0", 16 * (C2_PAIR + HAT)),
+    ("gemm_bf16_fused_argmax (C2; no volume)", "legs", "gemm_bf16op_kernel<128, 128, 2, 2, 1, 1", 16 * HAT + 16 * 4096 * 32 * 8),
+    ("gemm_f32_wide bwd_d_a (C2)", "legs", "gemm_f32_wide_kernel<true, true>", 16 * (C2_PAIR + 2 * HAT)),
+    ("gemm_f32_wide bwd_d_r (C2)", "legs", "gemm_f32_wide_kernel<true, false>", 16 * (C2_PAIR + 2 * HAT)),
+    ("corr_normalise (one of two launches; fp32 + bf16 images in the mix)", "legs", "corr_normalise_keep_kernel", 16 * 2 * HAT),
     ("corr_normalise_bwd", "legs", "corr_normalise_bwd_keep_kernel", 16 * 3 * HAT),
-    ("warp_fwd align_set 256^2 x128 (C3)", "legs", "warp_fwd_kernel<false, true, 1, true>", NPIX_C3 * 40),
+    ("warp_fwd align_set 256^2 x128 (C3)", "legs", "warp_fwd_kernel<false, true, 1, true", NPIX_C3 * 40),
     ("warp_bwd grad-grid 256^2 x128 (C3)", "legs", "warp_bwd_kernel<false, false, true, true>", NPIX_C3 * 40),
     ("warp_bwd grad-grid + grad-input (tiled)", "legs", "warp_bwd_tile_kernel<false, true, true>", NPIX_C3 * 52),
-    ("warp_fwd affine 240x424 x320 (C4)", "legs", "warp_fwd_kernel<true, true, 2, true>", NPIX_C4 * 32),
+    ("warp_fwd affine 240x424 x320 (C4)", "legs", "warp_fwd_kernel<true, true, 2, true", NPIX_C4 * 32),
     ("warp_bwd theta gradient (C4, tiled)", "legs", "warp_bwd_tile_kernel<true, false, true>", NPIX_C4 * 24),
     ("ctx_sim (C4, 32 targets)", "legs", "ctx_sim_kernel", CF),
     ("ctx_aggregate (C4)", "legs", "ctx_aggregate_kernel", CF + 32 * 257 * 30 * 53 * 4),
-    ("ctx_bwd_dmatch (C4)", "legs", "ctx_bwd_dmatch_kernel", CF),
+    ("ctx_bwd_dmatch (C4)", "legs", "ctx_bwd_dmatch_kernel", CF * 10 // 11 + 2 * 32 * 128 * 30 * 53 * 4),
     ("ctx_bwd_feats (C4)", "legs", "ctx_bwd_feats_", 2 * CF + 32 * 257 * 30 * 53 * 4),
     ("ref_importance (C4)", "legs", "ref_importance_kernel", 32 * 3 * 11 * 240 * 424 * 4),
 ]
 
 
 def main():
-    raw = {"legs": json.load(open(os.path.join(HERE, "r2_legs_hbm_bytes_raw.json")))}
+    raw = {"legs": json.load(open(os.path.join(HERE, "r3_legs_hbm_bytes_raw.json")))}
     out = {"_method": __doc__.strip()}
     for label, src, needle, algo in ROWS:
         hit = [v for k, v in raw[src].items() if needle in k]
