@@ -96,6 +96,15 @@ def corr_c2():
                 cot=rng.standard_normal((B, F_, S, S, S, S)).astype(F32))
 
 
+def corr_c2_batch():
+    """configs[1] at its full batch: 16 pairs of 64 x 64 maps, C = 256 (a 1 GiB volume and a 1 GiB cotangent)."""
+    rng = np.random.default_rng(2016)
+    B, C, F_, S = 16, 256, 1, 64
+    return dict(x_t=rng.standard_normal((B, C, S, S), dtype=F32), x_r=rng.standard_normal((B, C, F_, S, S), dtype=F32),
+                v_t=(rng.random((B, 1, S, S)) >= 0.1).astype(F32), v_r=(rng.random((B, 1, F_, S, S)) >= 0.1).astype(F32),
+                cot=rng.standard_normal((B, F_, S, S, S, S), dtype=F32))
+
+
 def corr_c3():
     """The alignment model's shape (C1 / C3): 16 x 16 x 512, 4 references, post-ReLU-like features incl. all-zero pixels."""
     rng = np.random.default_rng(2003)

@@ -109,6 +109,27 @@ def test_gpu_corr_config(gold, name, precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
+def test_gpu_corr_c2_full_batch_vs_reference(precision):
+    """BASELINE configs[1] at its FULL batch (16 pairs, 64 x 64, C = 256; a 1 GiB volume, fwd + bwd) against checksums of the real
+    reference run on the same inputs (tests/golden/corr_c2_batch.npz from make_golden_corr_c2_batch.py): fp32 and bf16x3 at the
+    fp32 bar, bf16 at its 1e-2 bar.  (the reference checksum used to cover one pair.)"""
+    import torch
+    from master_thesis_amd.utils import correlation
+    z = np.load(os.path.join(GOLDEN_DIR, "corr_c2_batch.npz"), allow_pickle=False)
+    ref = lambda prefix: {k[len(prefix) + 1:]: z[k] for k in z.files if k.startswith(prefix + "/")}
+    d = cc.corr_c2_batch()
+    xt, xr = T(d["x_t"], True), T(d["x_r"], True)
+    out = correlation.compute_masked_4d_correlation(xt, T(d["v_t"]), xr, T(d["v_r"]), precision=precision)
+    gt, gr = torch.autograd.grad(out, [xt, xr], grad_outputs=T(d["cot"]))
+    rtol, atol = (1e-2, 1e-3) if precision == "bf16" else (1e-4, 1e-5)
+    cc.check_float(N(out), ref("corr_c2_batch/out"), rtol=rtol, atol=atol, what="out (%s)" % precision)
+    del out
+    cc.check_float(N(gt), ref("corr_c2_batch/g_x_t"), rtol=rtol, atol=atol * 10, what="g_x_t (%s)" % precision)
+    cc.check_float(N(gr), ref("corr_c2_batch/g_x_r"), rtol=rtol, atol=atol * 10, what="g_x_r (%s)" % precision)
+
+
+@pytest.mark.gpu
 def test_gpu_align_config(gold):
     import torch
     from master_thesis_amd.utils import flow
