@@ -39,6 +39,23 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(dev):
+    """Make `dev` the current HIP device for the launches inside: a no-op when it already is (the one-GPU-per-process case: the
+    torch.cuda.device context manager costs several microseconds per call, a third of the host time of a one-pair inference call)."""
+    return _NO_SWITCH if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+
 def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -86,7 +103,7 @@ class Corr4dFn(torch.autograd.Function):
         out = torch.empty((b, f, h, w, h, w), dtype=torch.float32, device=dev)
         lib = _lib.lib()
         ws = _workspace(lib.tcl_corr4d_fwd_workspace_bytes(b, c, f, p, precision), dev, cache=not any(ctx.needs_input_grad))
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_corr4d_fwd", _p(xt), _p(vt), _p(xr), _p(vr), _p(out), b, c, f, p, precision,
                       _p(ws), ws.numel(), _stream(dev))
         ctx.save_for_backward(xt, vt, xr, vr, ws)
@@ -107,7 +124,7 @@ class Corr4dFn(torch.autograd.Function):
         if need_t or need_r:
             lib = _lib.lib()
             ws2 = _workspace(lib.tcl_corr4d_bwd_workspace_bytes(b, c, f, p, precision), dev)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.call("tcl_corr4d_bwd", _p(g), _p(xt), _p(vt), _p(xr), _p(vr), _p(ws), _p(g_t), _p(g_r),
                           b, c, f, p, precision, _p(ws2), ws2.numel(), _stream(dev))
         return g_t, None, g_r, None, None
@@ -145,7 +162,7 @@ def corr4d_argmax_flow(x_t, v_t, x_r, v_r, precision=None):
     vr = None if v_r is None else v_r.expand(b, 1, f, h, w).contiguous()
     flow = torch.empty((b, f, h, w, 2), dtype=torch.float32, device=dev)
     ws = _workspace(_lib.lib().tcl_corr4d_argmax_flow_workspace_bytes(b, c, f, p, prec), dev, cache=True)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.call("tcl_corr4d_argmax_flow", _p(xt), _p(vt), _p(xr), _p(vr), _p(flow), b, c, f, h, prec, _p(ws), ws.numel(), _stream(dev))
     return flow
 
@@ -160,7 +177,7 @@ class Corr1x1Fn(torch.autograd.Function):
         f1c, f2c = f1.contiguous(), f2.contiguous()
         m1c, m2c = m1.expand(b, 1, h, w).contiguous(), m2.expand(b, 1, h, w).contiguous()
         out = torch.empty((b, 1, h, w), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_corr1x1_fwd", _p(f1c), _p(f2c), _p(m1c), _p(m2c), _p(out), b, c, h * w, _stream(dev))
         ctx.save_for_backward(f1c, f2c, m1c, m2c)
         return out
@@ -174,7 +191,7 @@ class Corr1x1Fn(torch.autograd.Function):
         g = grad_out.contiguous()
         g1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
         g2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_corr1x1_bwd", _p(g), _p(f1), _p(f2), _p(m1), _p(m2), _p(g1), _p(g2), b, c, h * w, _stream(dev))
         return g1, g2, None, None
 
@@ -228,7 +245,7 @@ class WarpFn(torch.autograd.Function):
         x_out = torch.empty((b, f, c, h, w), dtype=torch.float32, device=dev)
         v_out = torch.empty((b, f, 1, h, w), dtype=torch.float32, device=dev) if vs is not None else None
         whole = len(runs) == 1 and runs[0][2] == f
-        with torch.cuda.device(dev):
+        with _on(dev):
             for src, dst, n in runs:
                 # the run's positions: rows b * F' + dst .. + n of grid / theta (a small dense copy unless the run is everything)
                 g_run = None if gridc is None else (gridc if whole else gridc.view(b, f, h, w, 2)[:, dst:dst + n].contiguous())
@@ -269,7 +286,7 @@ class WarpFn(torch.autograd.Function):
         g_theta = torch.empty_like(thetac) if (need_theta and thetac is not None) else None
         whole = len(runs) == 1 and runs[0][2] == f
         if need_x or g_grid is not None or g_theta is not None:
-            with torch.cuda.device(dev):
+            with _on(dev):
                 for src, dst, n in runs:
                     g_run = None if gridc is None else (gridc if whole else gridc.view(b, f, h, w, 2)[:, dst:dst + n].contiguous())
                     t_run = None if thetac is None else (thetac if whole else thetac.view(b, f, 2, 3)[:, dst:dst + n].contiguous())
@@ -311,16 +328,19 @@ def warp_infer(x_ref, m_ref, m_target, grid=None, theta=None, align_corners=True
     mt = mt if (mt.stride(2) == 1 and mt.stride(1) == w) else mt.contiguous()
     gridc = None if grid is None else grid.detach().reshape(b * f, h, w, 2).contiguous()
     thetac = None if theta is None else theta.detach().reshape(b * f, 2, 3).contiguous()
-    out = torch.empty((b, f, 5, h, w), dtype=torch.float32, device=dev)   # one allocation: frames (3), visibility, v_map
-    x_out, v_out, v_map = out[:, :, 0:3], out[:, :, 3:4], out[:, :, 4:5]
-    with torch.cuda.device(dev):
+    # one allocation, planes [frames (3), visibility, v_map] per batch item: the three results are plain channel slices of it (the C
+    # ABI takes strides, so no transposed views are needed on the way out)
+    out = torch.empty((b, 5, f, h, w), dtype=torch.float32, device=dev)
+    sb, sc, sf = 5 * f * h * w, f * h * w, h * w
+    base = out.data_ptr()
+    with _on(dev):
         _lib.call("tcl_warp_fwd_fused",
                   _p(xs), xs.stride(0), xs.stride(2), xs.stride(1), _p(ms), ms.stride(0), ms.stride(2), 1,
                   _p(gridc), _p(thetac),
-                  _p(x_out), out.stride(0), out.stride(1), out.stride(2), _p(v_out), out.stride(0), out.stride(1),
-                  _p(mt), mt.stride(0), 1, _p(v_map), out.stride(0), out.stride(1),
+                  ctypes.c_void_p(base), sb, sf, sc, ctypes.c_void_p(base + 3 * sc * 4), sb, sf,
+                  _p(mt), mt.stride(0), 1, ctypes.c_void_p(base + 4 * sc * 4), sb, sf,
                   b, f, 3, h, w, int(bool(align_corners)), _lib.VMODE_NEAREST if v_mode is None else v_mode, _stream(dev))
-    return x_out.transpose(1, 2), v_out.transpose(1, 2), v_map.transpose(1, 2)
+    return out[:, 0:3], out[:, 3:4], out[:, 4:5]
 
 
 def align_infer(x_ref, m_ref, flow, m_target):
@@ -341,7 +361,7 @@ class AffineGridFn(torch.autograd.Function):
             raise ValueError("affine_grid expects theta (N,2,3), got %s" % (tuple(theta.shape),))
         tc = theta.contiguous()
         grid = torch.empty((n, h, w, 2), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_affine_grid", _p(tc), _p(grid), n, h, w, int(bool(align_corners)), _stream(dev))
         ctx.meta = (h, w, bool(align_corners))
         return grid
@@ -363,7 +383,7 @@ def vmap(v_aligned, v_target):
     va = v_aligned.transpose(1, 2).contiguous()   # (B,F,1,H,W)
     vt = v_target.contiguous()
     out = torch.empty_like(va)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.call("tcl_vmap", _p(va), _p(vt), _p(out), b, f, h * w, _stream(dev))
     return out.transpose(1, 2)
 
@@ -404,7 +424,7 @@ class MaskedSoftmaxFn(torch.autograd.Function):
         dim, o, om, r, i, maskc = _softmax_layout(vec, mask, dim)
         vc = vec.contiguous()
         out = torch.empty_like(vc)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_masked_softmax_fwd", _p(vc), _p(maskc), _p(out), o, om, r, i, _stream(dev))
         ctx.save_for_backward(vc, maskc)
         ctx.layout = (o, om, r, i)
@@ -418,7 +438,7 @@ class MaskedSoftmaxFn(torch.autograd.Function):
         dev = vc.device
         g = grad_out.contiguous()
         gv = torch.empty_like(vc)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_masked_softmax_bwd", _p(g), _p(vc), _p(maskc), _p(gv), o, om, r, i, _stream(dev))
         return gv, None, None
 
@@ -444,7 +464,7 @@ class ContextMatchingFn(torch.autograd.Function):
         c_mask = torch.empty((b, 1, h, w), dtype=torch.float32, device=dev)
         c_match = torch.empty((b, r, h, w), dtype=torch.float32, device=dev)
         ws = _workspace(_lib.lib().tcl_ctx_workspace_bytes(b, c, r, h, w), dev, cache=not any(ctx.needs_input_grad))
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_ctx_fwd", _p(cf), _p(vt), _p(va), _p(p_in), _p(c_mask), _p(c_match), b, c, r, h, w, H, W,
                       variant, int(bool(normalize)), _p(ws), ws.numel(), _stream(dev))
         ctx.save_for_backward(cf, c_match, ws)
@@ -464,7 +484,7 @@ class ContextMatchingFn(torch.autograd.Function):
         gm = None if g_c_mask is None else g_c_mask.contiguous()
         g_cf = torch.empty_like(cf)
         ws2 = _workspace(_lib.lib().tcl_ctx_bwd_workspace_bytes(b, c, r, h, w), dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_ctx_bwd", _p(gp), _p(gm), _p(cf), _p(c_match), _p(ws), _p(g_cf), b, c, r, h, w, variant, normalize,
                       _p(ws2), ws2.numel(), _stream(dev))
         return g_cf, None, None, None, None
@@ -478,7 +498,7 @@ def ref_importance(c_match, v_t, middle_is_vt):
     cm = c_match.detach().contiguous()
     vt = v_t.detach().reshape(b, H, W).contiguous()
     out = torch.empty((b, 3, r + 1, H, W), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.call("tcl_ref_importance", _p(cm), _p(vt), _p(out), b, r, h, w, H, W, int(bool(middle_is_vt)), _stream(dev))
     return out
 
@@ -489,7 +509,7 @@ def resize_mask(v, size):
     n, ch, H, W = v.shape
     vc = v.contiguous()
     out = torch.empty((n, ch, size[0], size[1]), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.call("tcl_resize_mask", _p(vc), _p(out), n * ch, H, W, size[0], size[1], _stream(dev))
     return out
 
@@ -500,7 +520,7 @@ def dilate_cross3(img):
     H, W = img.shape[-2], img.shape[-1]
     ic = img.contiguous()
     out = torch.empty_like(ic)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.call("tcl_dilate_cross3", _p(ic), _p(out), ic.numel() // (H * W), H, W, _stream(dev))
     return out
 
@@ -513,7 +533,7 @@ def corr_to_flow(corr):
         raise ValueError("corr_to_flow expects (B,F,S,S,S,S), got %s" % (tuple(corr.shape),))
     cc = corr.detach().contiguous()
     flow = torch.empty((b, f, s, s, 2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.call("tcl_corr_to_flow", _p(cc), _p(flow), b * f, s, _stream(dev))
     return flow
 
@@ -526,7 +546,7 @@ class FlowAddIdentityFn(torch.autograd.Function):
         b, f, h, w, two = flow.shape
         fc = flow.contiguous()
         out = torch.empty_like(fc)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_flow_add_identity", _p(fc), _p(out), b * f, h, w, sign, _stream(dev))
         return out
 
@@ -546,7 +566,7 @@ class CropFlowFn(torch.autograd.Function):
         py, px = int(crop_position[0]), int(crop_position[1])
         fc = flow.contiguous()
         out = torch.empty((b, f, ch, cw, 2), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_crop_flow", _p(fc), _p(out), b * f, h, w, ch, cw, py, px, _stream(dev))
         ctx.meta = (b, f, h, w, ch, cw, py, px)
         return out
@@ -570,7 +590,7 @@ class ResizeFlowFn(torch.autograd.Function):
         oh, ow = int(size[0]), int(size[1])
         fc = flow.contiguous()
         out = torch.empty((b, f, oh, ow, 2), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.call("tcl_resize_flow", _p(fc), _p(out), b * f, h, w, oh, ow, _stream(dev))
         ctx.meta = (b, f, h, w, oh, ow)
         return out
