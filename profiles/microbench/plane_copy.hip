@@ -286,6 +286,30 @@ __global__ void __launch_bounds__(256) skew_lds_taps(const float *in, float *out
       for (int pl = 0; pl < NP; ++pl) __builtin_nontemporal_store(o[pl], op + pl * HW + y * W + x);
   }
 }
+
+// 4 consecutive pixels per lane: the same 8 tap loads per pixel (lanes now 16 bytes apart), 16-byte stores
+__global__ void __launch_bounds__(256) tap_x4store_copy(const float *in, float *out) {
+  const int n = blockIdx.z * 8 + blockIdx.x;
+  if (n >= NIMG) return;
+  const float *ip = in + (size_t)n * NP * HW; float *op = out + (size_t)n * NP * HW;
+  const unsigned q0 = blockIdx.y * 256 + threadIdx.x, q = min(q0 * 4, (unsigned)HW - W - 8);
+  F2U a[4][NP], b[4][NP];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      a[j][c] = *reinterpret_cast<const F2U *>(reinterpret_cast<const char *>(ip + c * HW) + ((q + j) << 2));
+      b[j][c] = *reinterpret_cast<const F2U *>(reinterpret_cast<const char *>(ip + c * HW) + ((q + j + W) << 2));
+    }
+  if (q0 * 4 < HW)
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      f4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = a[j][c].a * 0.25f + a[j][c].b * 0.25f + b[j][c].a * 0.25f + b[j][c].b * 0.25f;
+      __builtin_nontemporal_store(r, reinterpret_cast<f4 *>(op + c * HW) + q0);
+    }
+}
 template <typename F> float timeit(F f, int it = 10) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int i = 0; i < 2; ++i) f();
@@ -319,6 +343,7 @@ int main() {
   rep("8 dword + DPP, lane 63 loads own east", [&](const float *i, float *o) { tap_mode_copy<4><<<dim3(8, c1, NIMG / 8), 256>>>(i, o); });
   rep("8 dword + DPP, every 16th lane loads", [&](const float *i, float *o) { tap_mode_copy<5><<<dim3(8, c1, NIMG / 8), 256>>>(i, o); });
   rep("8 dword + DPP, 63 px per wave", [&](const float *i, float *o) { tap_mode_copy<6><<<dim3(8, (HW + 251) / 252, NIMG / 8), 256>>>(i, o); });
+  rep("8 tap loads, 4 consecutive px/lane, x4 stores", [&](const float *i, float *o) { tap_x4store_copy<<<dim3(8, (HW / 4 + 255) / 256, NIMG / 8), 256>>>(i, o); });
   rep("tile copy 64x32 (no LDS)", [&](const float *i, float *o) { tile_copy<32><<<dim3(8, tx * ((H + 31) / 32), NIMG / 8), 256>>>(i, o, tx); });
   rep("tile copy 64x16 (no LDS)", [&](const float *i, float *o) { tile_copy<16><<<dim3(8, tx * ((H + 15) / 16), NIMG / 8), 256>>>(i, o, tx); });
   rep("two aligned rows -> dword", [&](const float *i, float *o) { tworow_copy<<<dim3(8, c1, NIMG / 8), 256>>>(i, o); });
