@@ -104,7 +104,7 @@ __device__ __forceinline__ TapVals fetch_taps(const float *plane, const Taps &t,
 
 template <bool W2>
 __device__ __forceinline__ void select_taps(const TapVals &v, const Taps &t, float &a, float &b, float &c, float &d) {
-  const bool same = !W2 || t.xi == t.xa;   // false only at xi = -1 (east = .a) and xi = W-1 (west = .b)
+  const bool same = t.xi == t.xa;   // false only at xi = -1 (east = .a; also the one-pixel-wide image, where xa = 0) and xi = W-1 (west = .b)
   a = (t.yn & t.xw) ? (same ? v.n.a : v.n.b) : 0.f;
   b = (t.yn & t.xe) ? (same ? v.n.b : v.n.a) : 0.f;
   c = (t.ys & t.xw) ? (same ? v.s.a : v.s.b) : 0.f;

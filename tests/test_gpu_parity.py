@@ -447,6 +447,32 @@ def test_warp_generic_channel_counts(C, F, H, W):
     assert_close(N(gf), ogf, what="warp g_flow")
 
 
+@pytest.mark.parametrize("H,W", [(7, 1), (1, 5), (1, 1), (6, 9)])
+@pytest.mark.parametrize("align_corners", [False, True])
+def test_warp_thin_images_both_corner_conventions(H, W, align_corners):
+    """One-pixel-wide / -high images: with align_corners = False the sampled column is g / 2, so every negative grid value puts the WEST tap
+    outside and the east tap on column 0 (the kernel's clamped two-wide load must then hand out its first element).  Checked against
+    stock ATen on the CPU, forward and both gradients."""
+    from master_thesis_amd import _lib, _ops
+    import torch.nn.functional as Fn
+    rng = np.random.default_rng(H * 10 + W)
+    B, C, F = 2, 3, 2
+    x = rng.random((B, C, F, H, W)).astype(np.float32)
+    grid = (rng.random((B * F, H, W, 2)) * 2.4 - 1.2).astype(np.float32)
+    cot = rng.standard_normal((B, C, F, H, W)).astype(np.float32)
+    tx, tg = T(x, True), T(grid, True)
+    xa, _ = _ops.WarpFn.apply(tx, None, tg, None, align_corners, _lib.VMODE_NONE)
+    gx, gg = torch.autograd.grad((xa * T(cot)).sum(), [tx, tg])
+    cx = torch.tensor(x, requires_grad=True)
+    cg = torch.tensor(grid, requires_grad=True)
+    ref = Fn.grid_sample(cx.transpose(1, 2).reshape(B * F, C, H, W), cg, mode="bilinear", padding_mode="zeros", align_corners=align_corners)
+    ref = ref.reshape(B, F, C, H, W).transpose(1, 2)
+    rgx, rgg = torch.autograd.grad((ref * torch.tensor(cot)).sum(), [cx, cg])
+    assert_close(N(xa), ref.detach().numpy(), what="thin warp x")
+    assert_close(N(gx), rgx.numpy(), what="thin warp g_x")
+    assert_close(N(gg), rgg.numpy(), what="thin warp g_grid")
+
+
 @pytest.mark.parametrize("C,H,W,scale,rot,jitter", [
     (3, 64, 128, 1.0, 0.0, 0.0),       # exact identity: every north / south and east / west pair merges
     (3, 96, 200, 1.08, 0.15, 0.001),   # upscaling + rotation: columns skip, rows drift
