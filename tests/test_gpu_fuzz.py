@@ -186,3 +186,47 @@ def test_fuzz_masked_softmax(seed, b, r, h, w):
     assert_close(N(out), O.masked_softmax(vec, mask, 2), what="masked_softmax fwd")
     (g,) = torch.autograd.grad((out * T(cot)).sum(), [tv])
     assert_close(N(g), O.masked_softmax_bwd(vec, mask, 2, cot), what="masked_softmax bwd")
+
+
+def _argmax_cases():
+    rng = np.random.default_rng(5)
+    return [(i, int(rng.integers(1, 4)), int(rng.choice([1, 5, 32, 48, 100, 256])), int(rng.integers(1, 4)), int(rng.choice([2, 3, 7, 8, 12, 16, 31])),
+             int(rng.integers(0, 3)), int(rng.integers(0, 3))) for i in range(40)]
+
+
+@pytest.mark.parametrize("seed,b,c,f,s_,prec,kmask", _argmax_cases())
+def test_fuzz_fused_argmax_equals_unfused(seed, b, c, f, s_, prec, kmask):
+    """tcl_corr4d_argmax_flow == corr_to_flow(corr4d) at the same precision, bit for bit (first-maximum ties included: a fully masked
+    image makes every similarity of its rows equal)."""
+    from master_thesis_amd import _lib, _ops
+    rng = np.random.default_rng(1700 + seed)
+    xt = rng.standard_normal((b, c, s_, s_)).astype(np.float32)
+    xr = rng.standard_normal((b, c, f, s_, s_)).astype(np.float32)
+    vt, vr = _mask(rng, (b, 1, s_, s_), kmask), _mask(rng, (b, 1, f, s_, s_), (kmask + seed) % 3)
+    precision = (_lib.PREC_F32, _lib.PREC_BF16X3, _lib.PREC_BF16)[prec]
+    fused = _ops.corr4d_argmax_flow(T(xt), T(vt), T(xr), T(vr), precision=precision)
+    vol = _ops.corr4d(T(xt), T(vt), T(xr), T(vr), precision=precision)
+    assert_exact(N(fused), N(_ops.corr_to_flow(vol)), what="fused argmax vs unfused")
+
+
+def _infer_cases():
+    rng = np.random.default_rng(9)
+    return [(i, int(rng.integers(1, 3)), int(rng.integers(1, 4)), int(rng.choice([2, 3, 16, 33, 64, 90])), int(rng.choice([2, 5, 31, 64, 65, 130])))
+            for i in range(24)]
+
+
+@pytest.mark.parametrize("seed,b,f,h,w", _infer_cases())
+def test_fuzz_inference_unit_equals_unfused(seed, b, f, h, w):
+    """align_infer (one launch: hole masks flipped per tap, v_map in the epilogue) == align_set(x, 1 - m, flow) + vmap, bit for bit."""
+    from master_thesis_amd import _ops
+    from master_thesis_amd.utils import flow as tflow
+    rng = np.random.default_rng(2100 + seed)
+    x = rng.random((b, 3, f, h, w)).astype(np.float32)
+    m = (rng.random((b, 1, f, h, w)) < 0.3).astype(np.float32)
+    mt = (rng.random((b, 1, h, w)) < 0.3).astype(np.float32)
+    fl = (rng.random((b, f, h, w, 2)) * 2.3 - 1.15).astype(np.float32)
+    xa, va, vm = _ops.align_infer(T(x), T(m), T(fl), T(mt))
+    xa0, va0 = tflow.align_set(T(x), 1 - T(m), T(fl))
+    assert_exact(N(xa), N(xa0), what="x_aligned")
+    assert_exact(N(va), N(va0), what="v_aligned")
+    assert_exact(N(vm), N(_ops.vmap(va0, 1 - T(mt))), what="v_map")
