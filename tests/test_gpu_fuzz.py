@@ -230,3 +230,37 @@ def test_fuzz_inference_unit_equals_unfused(seed, b, f, h, w):
     assert_exact(N(xa), N(xa0), what="x_aligned")
     assert_exact(N(va), N(va0), what="v_aligned")
     assert_exact(N(vm), N(_ops.vmap(va0, 1 - T(mt))), what="v_map")
+
+
+def _mid_cases():
+    rng = np.random.default_rng(13)
+    sizes = [(24, 24), (32, 32), (40, 40), (48, 48), (56, 56), (64, 64), (30, 53), (20, 77)]
+    return [(i, int(rng.integers(1, 3)), int(rng.choice([64, 96, 200, 256, 512])), int(rng.integers(1, 3)),
+             *sizes[int(rng.integers(0, len(sizes)))], int(rng.integers(0, 3))) for i in range(18)]
+
+
+@pytest.mark.parametrize("seed,b,c,f,h,w,prec", _mid_cases())
+def test_fuzz_corr4d_mid_sizes(seed, b, c, f, h, w, prec):
+    """Map sizes around the tile and wide-kernel eligibility edges (P = 576 ... 4096, not all multiples of 128 / 256), checked against
+    the same formula in fp64 on the GPU (stock torch ops; the numpy oracle takes too long at these sizes)."""
+    from master_thesis_amd import _lib, _ops
+    g = torch.Generator(device="cpu").manual_seed(3000 + seed)
+    xt = torch.randn(b, c, h, w, generator=g).to(DEV).requires_grad_(True)
+    xr = torch.randn(b, c, f, h, w, generator=g).to(DEV).requires_grad_(True)
+    vt = (torch.rand(b, 1, h, w, generator=g) < 0.8).float().to(DEV)
+    vr = (torch.rand(b, 1, f, h, w, generator=g) < 0.8).float().to(DEV)
+    cot = torch.randn(b, f, h, w, h, w, generator=g).to(DEV)
+    precision = (_lib.PREC_F32, _lib.PREC_BF16X3, _lib.PREC_BF16)[prec]
+    out = _ops.corr4d(xt, vt, xr, vr, precision=precision)
+    g_t, g_r = torch.autograd.grad((out * cot).sum(), [xt, xr])
+    xt64, xr64 = xt.detach().double().requires_grad_(True), xr.detach().double().requires_grad_(True)
+    a = (xt64 * vt.double()).reshape(b, c, h * w)
+    r = (xr64 * vr.double()).reshape(b, c, f, h * w)
+    a = a / (a.norm(dim=1, keepdim=True) + 1e-9)
+    r = r / (r.norm(dim=1, keepdim=True) + 1e-9)
+    ref = torch.einsum("bcp,bcfq->bfpq", a, r).reshape(b, f, h, w, h, w)
+    rg_t, rg_r = torch.autograd.grad((ref * cot.double()).sum(), [xt64, xr64])
+    rtol, atol = (1e-2, 1e-2) if precision == _lib.PREC_BF16 else (1e-4, 1e-5)
+    assert_close(N(out), N(ref), rtol=rtol, atol=atol, what="corr fwd")
+    assert_close(N(g_t), N(rg_t), rtol=rtol, atol=atol, what="corr g_x_t")
+    assert_close(N(g_r), N(rg_r), rtol=rtol, atol=atol, what="corr g_x_r")
