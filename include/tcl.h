@@ -74,9 +74,9 @@ const char *tcl_last_error(void);
  *     utils/correlation.py:28-54.
  *   x_t (B,C,P)  v_t (B,P) nullable   x_r (B,C,F,P)  v_r (B,F,P) nullable   P = H*W
  *   out (B,F,P,P): out[b,f,p,q] = <a^[b,:,p], r^[b,f,:,q]>, a^ = x v / (||x v||_2 + 1e-9).
- *   The forward leaves the normalised operands and the norms in `workspace` (fp32 images in every variant; the bf16
- *   variants add the bf16 (hi, lo) images their contraction reads); pass the same buffer, unmodified, to tcl_corr4d_bwd
- *   as `fwd_workspace`.
+ *   The forward leaves the normalised operands and the norms in `workspace` (TCL_PREC_F32: fp32 images; the bf16 variants:
+ *   the bf16 hi (and lo) images that their forward AND backward products read, and no fp32 image); pass the same buffer,
+ *   unmodified and with the same `precision`, to tcl_corr4d_bwd as `fwd_workspace`.
  * ------------------------------------------------------------------------------------------- */
 size_t tcl_corr4d_fwd_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P, int precision);
 int tcl_corr4d_fwd(const float *x_t, const float *v_t, const float *x_r, const float *v_r, float *out,

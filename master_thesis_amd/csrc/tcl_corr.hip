@@ -1115,6 +1115,47 @@ struct TileLoaderH {
   }
 };
 
+// A k-contiguous operand that already IS a bf16 image in global memory (the hi / lo images corr_normalise* leaves in the forward
+// workspace): 16-byte pieces (8 k's of one row) straight into the [row][k] LDS image, no conversion in the loop.
+struct Bf16Ops { const __bf16 *a_hi, *a_lo, *b_hi, *b_lo; };
+
+template <int ROWS, int NT>
+struct TileLoaderKC16 {
+  static constexpr int NV = ROWS * BKH / 8 / NT;
+  static_assert(ROWS * BKH / 8 % NT == 0 && NV >= 1, "tile must divide over the block");
+  u32x4 r[NV];
+  __device__ __forceinline__ static void thread_offsets(uint32_t (&off)[NV], int64_t ld, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      off[i] = ((uint32_t)(idx / (BKH / 8)) * (uint32_t)ld + (uint32_t)(idx % (BKH / 8)) * 8u) * 2u;
+    }
+  }
+  __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rsrc, const uint32_t (&off)[NV], int soff) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off[i], soff, 0);
+  }
+  __device__ __forceinline__ void load(const __bf16 *base, int64_t ld, int row0, int k0, int rows, int depth, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT, row = row0 + idx / (BKH / 8), k = k0 + (idx % (BKH / 8)) * 8;
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (row < rows && k + j < depth) ? reinterpret_cast<const unsigned short *>(base)[(int64_t)row * ld + k + j] : (unsigned short)0;
+      const u32x4 v = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
+                       (unsigned)e[6] | ((unsigned)e[7] << 16)};
+      r[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(__bf16 *img, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      *reinterpret_cast<u32x4 *>(img + (idx / (BKH / 8)) * KC_LDH + (idx % (BKH / 8)) * 8) = r[i];
+    }
+  }
+};
+
 // fragment of the 32x32x16 MFMA for the 32 rows starting at row0, k-step ks (0/1) of the staged tile:
 // lane (r = lane & 31, h = lane >> 5) gets element (row0 + r, k = 16 ks + 8 h + j), j = 0..7.
 template <int ROWS, bool KC>
@@ -1132,8 +1173,12 @@ __device__ __forceinline__ bf16x8 read_frag_h(const __bf16 *img, int row0, int k
   return f;
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int NS, bool FULL = false>
-__global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
+// A16: the A operand comes from the bf16 hi (/ lo) images `o.a_hi / o.a_lo` (same element order as g.A would have: the backward
+// products take r^ / a^ this way, bit-identical to converting the fp32 image in the loop and two thirds of the loop's conversion
+// work gone); B (the cotangent volume) is fp32 and converted while it is staged.
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool VEC, int NS, bool FULL = false, bool A16 = false>
+__global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g, Bf16Ops o) {
+  static_assert(!A16 || A_KC, "bf16 operand images are k-contiguous");
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_IMG = ImgSize<BM, A_KC>::value, B_IMG = ImgSize<BN, B_KC>::value;
@@ -1154,8 +1199,10 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
   const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
   const int lr = lane & 31, lh = lane >> 5;
 
-  const float *Ab = g.A + (int64_t)(z / g.a_bdiv) * g.a_bs;
+  const float *Ab = A16 ? nullptr : g.A + (int64_t)(z / g.a_bdiv) * g.a_bs;
   const float *Bb = g.B + (int64_t)z * g.b_bs;
+  const __bf16 *A16h = A16 ? o.a_hi + (int64_t)(z / g.a_bdiv) * g.a_bs : nullptr;
+  const __bf16 *A16l = (A16 && NS == 2) ? o.a_lo + (int64_t)(z / g.a_bdiv) * g.a_bs : nullptr;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -1167,29 +1214,53 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
 
   TileLoaderH<BM, NT, A_KC, VEC, NS> la;
   TileLoaderH<BN, NT, B_KC, VEC, NS> lb;
+  TileLoaderKC16<BM, NT> la16[NS];
   const int ktiles = (g.K + BKH - 1) / BKH;
   const int total = ktiles * g.nseg;
 
   // FULL: buffer-load cursors as in gemm_f32_kernel (descriptor + loop-invariant offsets + scalar k offset; the launcher
   // checks the 31-bit bound)
   const int64_t a_k = la.kstep(g.a_ld), b_k = lb.kstep(g.b_ld);
-  uint32_t a_off[la.NV], b_off[lb.NV];
-  __amdgpu_buffer_rsrc_t ra, rb;
-  int sa = 0, sb = 0;
+  uint32_t a_off[la.NV], b_off[lb.NV], a16_off[la16[0].NV];
+  __amdgpu_buffer_rsrc_t ra, rb, ra16[NS];
+  int sa = 0, sb = 0;   // sa counts ELEMENTS x 4 (bytes of the fp32 image; the bf16 images take half)
   if (FULL) {
-    la.thread_offsets(a_off, g.a_ld, tid);
+    if (A16) {
+      la16[0].thread_offsets(a16_off, g.a_ld, tid);
+      ra16[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(A16h + (int64_t)m0 * g.a_ld), 0, 0x7fffffff, 0x00020000);
+      if (NS == 2) ra16[NS - 1] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(A16l + (int64_t)m0 * g.a_ld), 0, 0x7fffffff, 0x00020000);
+    } else {
+      la.thread_offsets(a_off, g.a_ld, tid);
+      ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Ab + (A_KC ? (int64_t)m0 * g.a_ld : m0)), 0, 0x7fffffff, 0x00020000);
+    }
     lb.thread_offsets(b_off, g.b_ld, tid);
-    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Ab + (A_KC ? (int64_t)m0 * g.a_ld : m0)), 0, 0x7fffffff, 0x00020000);
     rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Bb + (B_KC ? (int64_t)n0 * g.b_ld : n0)), 0, 0x7fffffff, 0x00020000);
   }
+  auto load_a = [&](int t_abs) {   // k-tile t_abs (over the segments) of A into registers
+    if (A16) {
+      if (FULL) {
+#pragma unroll
+        for (int h = 0; h < NS; ++h) la16[h].load_buf(ra16[h], a16_off, sa / 2);
+      } else {
+        const int seg = t_abs / ktiles, kt = t_abs - seg * ktiles;
+        la16[0].load(A16h + seg * g.a_ss, g.a_ld, m0, kt * BKH, g.M, g.K, tid);
+        if (NS == 2) la16[NS - 1].load(A16l + seg * g.a_ss, g.a_ld, m0, kt * BKH, g.M, g.K, tid);
+      }
+    } else if (FULL) la.load_buf(ra, a_off, sa);
+    else {
+      const int seg = t_abs / ktiles, kt = t_abs - seg * ktiles;
+      la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BKH, g.M, g.K, tid);
+    }
+  };
   int kt_next = 1;
-  if (FULL) { la.load_buf(ra, a_off, 0); lb.load_buf(rb, b_off, 0); }
-  else {
-    la.load(Ab, g.a_ld, m0, 0, g.M, g.K, tid);
-    lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
-  }
+  load_a(0);
+  if (FULL) lb.load_buf(rb, b_off, 0);
+  else lb.load(Bb, g.b_ld, n0, 0, g.N, g.K, tid);
   for (int t = 0; t < total; ++t) {
-    la.store(Ah, Al, tid);
+    if (A16) {
+      la16[0].store(Ah, tid);
+      if (NS == 2) la16[NS - 1].store(Al, tid);
+    } else la.store(Ah, Al, tid);
     lb.store(Bh, Bl, tid);
     __syncthreads();
     if (t + 1 < total) {
@@ -1197,11 +1268,11 @@ __global__ void __launch_bounds__(WM *WN * 64) gemm_bf16_kernel(GemmArgs g) {
         if (kt_next == ktiles) { kt_next = 0; sa += (int)(g.a_ss - (ktiles - 1) * a_k) * 4; sb += (int)(g.b_ss - (ktiles - 1) * b_k) * 4; }
         else { sa += (int)a_k * 4; sb += (int)b_k * 4; }
         ++kt_next;
-        la.load_buf(ra, a_off, sa);
+        load_a(t + 1);
         lb.load_buf(rb, b_off, sb);
       } else {
         const int seg = (t + 1) / ktiles, kt = (t + 1) - seg * ktiles;
-        la.load(Ab + seg * g.a_ss, g.a_ld, m0, kt * BKH, g.M, g.K, tid);
+        load_a(t + 1);
         lb.load(Bb + seg * g.b_ss, g.b_ld, n0, kt * BKH, g.N, g.K, tid);
       }
     }
@@ -1327,8 +1398,6 @@ struct TileLoaderB {
     }
   }
 };
-
-struct Bf16Ops { const __bf16 *a_hi, *a_lo, *b_hi, *b_lo; };
 
 // Pipeline (the wide fp32 kernel's, with two 16-deep MFMA groups per 32-deep k-tile): two LDS stages and ONE barrier per k-tile,
 // placed between the tile's two groups.  Before it a wave reads its group-1 fragments, writes its share of the NEXT tile to the
@@ -1540,28 +1609,33 @@ static bool gemm_vec_ok(const GemmArgs &g, bool a_kc, bool b_kc) {
          g.a_ss % 4 == 0 && g.b_ss % 4 == 0 && (a_kc ? g.K % 4 == 0 : g.M % 4 == 0) && (b_kc ? g.K % 4 == 0 : g.N % 4 == 0);
 }
 
+// A operand from the bf16 images in `o` (a_hi, a_lo for nsplit == 2), B = g.B in fp32
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
-static int launch_gemm_bf16(GemmArgs g, int nsplit, hipStream_t s, const char *what) {
+static int launch_gemm_bf16(GemmArgs g, const Bf16Ops &o, int nsplit, hipStream_t s, const char *what) {
+  TCL_REQUIRE(o.a_hi && (nsplit == 1 || o.a_lo), TCL_ERR_ARG, "%s: bf16 operand images missing", what);
   g.tiles_m = (int)cdiv(g.M, BM);
   g.tiles_n = (int)cdiv(g.N, BN);
   g.d_vec = aligned(g.D, 16) && g.d_ld % 4 == 0 && g.d_bs % 4 == 0;
   const int64_t blocks = (int64_t)g.tiles_m * g.tiles_n * g.nbatch;
   TCL_REQUIRE(blocks > 0 && blocks < (1LL << 31), TCL_ERR_SHAPE, "%s: grid of %ld blocks", what, (long)blocks);
-  const bool vec = gemm_vec_ok(g, A_KC, B_KC);
+  // B (fp32) alone decides the vector width of the ragged path; the full-tile path also needs 16-byte aligned rows of the bf16 images
+  GemmArgs gb = g; gb.A = g.B; gb.a_ld = g.b_ld; gb.a_bs = g.b_bs; gb.a_ss = g.b_ss;
+  const bool vec = gemm_vec_ok(gb, B_KC, B_KC);
+  const bool a16_vec = aligned(o.a_hi, 16) && aligned(o.a_lo, 16) && g.a_ld % 8 == 0 && g.a_bs % 8 == 0 && g.a_ss % 8 == 0;
   const dim3 grd((unsigned)blocks), blk(WM * WN * 64);
-  if (vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BKH == 0 && (int64_t)BM * g.d_ld * 4 < (1LL << 31) &&
+  if (vec && a16_vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BKH == 0 && (int64_t)BM * g.d_ld * 4 < (1LL << 31) &&
       (int64_t)g.nseg * g.a_ss * 4 + (int64_t)(A_KC ? BM : g.K) * g.a_ld * 4 < (1LL << 31) &&
       (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? BN : g.K) * g.b_ld * 4 < (1LL << 31)) {   // full tiles (31-bit buffer offsets): cursor loads, no predication
-    if (nsplit == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 2, true>), grd, blk, 0, s, g);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 1, true>), grd, blk, 0, s, g);
+    if (nsplit == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 2, true, true>), grd, blk, 0, s, g, o);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 1, true, true>), grd, blk, 0, s, g, o);
     return check_launch(what);
   }
   if (nsplit == 2) {
-    if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 2>), grd, blk, 0, s, g);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, false, 2>), grd, blk, 0, s, g);
+    if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 2, false, true>), grd, blk, 0, s, g, o);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, false, 2, false, true>), grd, blk, 0, s, g, o);
   } else {
-    if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 1>), grd, blk, 0, s, g);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, false, 1>), grd, blk, 0, s, g);
+    if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 1, false, true>), grd, blk, 0, s, g, o);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, false, 1, false, true>), grd, blk, 0, s, g, o);
   }
   return check_launch(what);
 }
@@ -1572,9 +1646,10 @@ struct CorrWs {
   __bf16 *a_hi, *r_hi, *a_lo, *r_lo;     // bf16 operand images (TCL_PREC_BF16: hi; TCL_PREC_BF16X3: hi + lo), same element order
   size_t bytes;
 };
-// Layout: [a^ r^ fp32 (keep_f32)] [norms] [a^ r^ hi (bf16 variants)] [a^ r^ lo (bf16x3)].  The fp32 images come first, so the
-// backward pass (which multiplies the fp32 operands in every variant) finds them where the fp32 forward leaves them.
-static CorrWs corr_ws(void *base, int64_t B, int64_t C, int64_t F, int64_t P, int precision, bool keep_f32 = true) {
+// Layout: [a^ r^ fp32 (TCL_PREC_F32 only)] [norms] [a^ r^ hi (bf16 variants)] [a^ r^ lo (bf16x3)]: every variant keeps exactly the
+// operand images its forward and backward products multiply.
+static CorrWs corr_ws(void *base, int64_t B, int64_t C, int64_t F, int64_t P, int precision) {
+  const bool keep_f32 = precision == TCL_PREC_F32;   // the bf16 variants multiply the bf16 images in the forward AND the backward products
   CorrWs w{};
   size_t off = 0;
   auto take = [&](size_t nbytes) { void *p = (char *)base + off; off += round_up(nbytes, 256); return p; };
@@ -1812,7 +1887,7 @@ extern "C" int tcl_corr4d_contract(const void *fwd_workspace, float *out, int64_
 constexpr int ARGMAX_BN = 128;
 extern "C" size_t tcl_corr4d_argmax_flow_workspace_bytes(int64_t B, int64_t C, int64_t F, int64_t P, int precision) {
   if (B <= 0 || C <= 0 || F <= 0 || P <= 0) return 0;
-  return corr_ws(nullptr, B, C, F, P, precision, precision == TCL_PREC_F32).bytes + round_up((size_t)B * F * P * cdiv(P, ARGMAX_BN) * sizeof(float2), 256);
+  return corr_ws(nullptr, B, C, F, P, precision).bytes + round_up((size_t)B * F * P * cdiv(P, ARGMAX_BN) * sizeof(float2), 256);
 }
 
 extern "C" int tcl_corr4d_argmax_flow(const float *x_t, const float *v_t, const float *x_r, const float *v_r, float *flow, int64_t B,
@@ -1826,8 +1901,7 @@ extern "C" int tcl_corr4d_argmax_flow(const float *x_t, const float *v_t, const 
   TCL_REQUIRE(workspace && aligned(workspace, 256) && workspace_bytes >= need, TCL_ERR_WORKSPACE,
               "tcl_corr4d_argmax_flow: workspace of %zu bytes (256-aligned) needed, got %zu", need, workspace_bytes);
   hipStream_t s = (hipStream_t)stream;
-  // inference only (no backward pass follows): the bf16 variants write just the bf16 operand images
-  const CorrWs w = corr_ws(workspace, B, C, F, P, precision, precision == TCL_PREC_F32);
+  const CorrWs w = corr_ws(workspace, B, C, F, P, precision);
   float2 *part = (float2 *)((char *)workspace + w.bytes);
   const dim3 blk(256);
   launch_normalise(s, x_t, v_t, HatOut{w.a_hat, w.a_hi, w.a_lo}, w.n_t, B, (int)C, 1, P);
@@ -1878,7 +1952,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_ld = P; g.b_ld = P; g.d_ld = P;
     g.a_bs = F * C * P; g.b_bs = F * P * P; g.d_bs = C * P;
     g.a_ss = C * P; g.b_ss = P * P; g.a_bdiv = 1; g.nbatch = (int)B;
-    if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, true>(g, nsplit, s, "tcl_corr4d_bwd(d_a bf16 gemm)");
+    if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, true>(g, Bf16Ops{w.r_hi, w.r_lo, nullptr, nullptr}, nsplit, s, "tcl_corr4d_bwd(d_a bf16 gemm)");
     else if (gemm_wide_ok(g, true, true) && wide_kernel_ready<true, true>()) rc = launch_gemm_wide<true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
     else rc = launch_gemm<256, 128, 4, 2, true, true>(g, s, "tcl_corr4d_bwd(d_a gemm)");
     if (rc) return rc;
@@ -1894,7 +1968,7 @@ extern "C" int tcl_corr4d_bwd(const float *grad_out, const float *x_t, const flo
     g.a_ld = P; g.b_ld = P; g.d_ld = P;
     g.a_bs = C * P; g.b_bs = P * P; g.d_bs = C * P;
     g.a_ss = 0; g.b_ss = 0; g.a_bdiv = (int)F; g.nbatch = (int)(B * F);
-    if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, false>(g, nsplit, s, "tcl_corr4d_bwd(d_r bf16 gemm)");
+    if (precision != TCL_PREC_F32) rc = launch_gemm_bf16<256, 128, 4, 2, true, false>(g, Bf16Ops{w.a_hi, w.a_lo, nullptr, nullptr}, nsplit, s, "tcl_corr4d_bwd(d_r bf16 gemm)");
     else if (gemm_wide_ok(g, true, false) && wide_kernel_ready<true, false>()) rc = launch_gemm_wide<true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
     else rc = launch_gemm<256, 128, 4, 2, true, false>(g, s, "tcl_corr4d_bwd(d_r gemm)");
     if (rc) return rc;
