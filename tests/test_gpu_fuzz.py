@@ -264,3 +264,37 @@ def test_fuzz_corr4d_mid_sizes(seed, b, c, f, h, w, prec):
     assert_close(N(out), N(ref), rtol=rtol, atol=atol, what="corr fwd")
     assert_close(N(g_t), N(rg_t), rtol=rtol, atol=atol, what="corr g_x_t")
     assert_close(N(g_r), N(rg_r), rtol=rtol, atol=atol, what="corr g_x_r")
+
+
+def _flow_cases():
+    rng = np.random.default_rng(17)
+    out = []
+    for i in range(30):
+        b, f = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+        h, w = int(rng.choice([2, 3, 8, 17, 64, 90])), int(rng.choice([2, 5, 16, 33, 64, 130]))
+        ch, cw = int(rng.integers(1, h + 1)), int(rng.integers(1, w + 1))
+        out.append((i, b, f, h, w, ch, cw, int(rng.integers(0, h - ch + 1)), int(rng.integers(0, w - cw + 1)),
+                    int(rng.choice([1, 2, 7, 16, 50, 128])), int(rng.choice([1, 3, 8, 31, 64, 200]))))
+    return out
+
+
+@pytest.mark.parametrize("seed,b,f,h,w,ch,cw,py,px,rh,rw", _flow_cases())
+def test_fuzz_flow_utils(seed, b, f, h, w, ch, cw, py, px, rh, rw):
+    """A11-A13: identity-grid add / subtract, crop (python-float scale factors) and legacy-nearest resize, values and indices exact."""
+    from master_thesis_amd.utils import flow as tflow
+    rng = np.random.default_rng(2500 + seed)
+    fl = (rng.random((b, f, h, w, 2)) * 2.4 - 1.2).astype(np.float32)
+    assert_exact(N(tflow.flow_abs_to_relative(T(fl))), O.flow_abs_to_relative(fl), what="abs -> relative")
+    assert_exact(N(tflow.flow_relative_to_abs(T(fl))), O.flow_relative_to_abs(fl), what="relative -> abs")
+    assert_exact(N(tflow.resize_flow(T(fl), (rh, rw))), O.resize_flow(fl, (rh, rw)), what="resize_flow")
+    if h > 1 and w > 1 and ch > 0 and cw > 0:
+        assert_close(N(tflow.crop_flow(T(fl), (ch, cw), (py, px))), O.crop_flow(fl, (ch, cw), (py, px)), rtol=1e-6, atol=1e-6, what="crop_flow")
+
+
+@pytest.mark.parametrize("seed,b,f,s_", [(i, 1 + i % 3, 1 + i % 2, s_) for i, s_ in enumerate([2, 3, 5, 8, 13, 16, 24, 32])])
+def test_fuzz_corr_to_flow_with_ties(seed, b, f, s_):
+    """First-maximum argmax over volumes quantised to a few levels (ties everywhere), indices exact."""
+    from master_thesis_amd.utils import flow as tflow
+    rng = np.random.default_rng(2900 + seed)
+    vol = (rng.integers(0, 4, (b, f, s_, s_, s_, s_)) / 4.0).astype(np.float32)
+    assert_exact(N(tflow.corr_to_flow(T(vol))), O.corr_to_flow(vol), what="corr_to_flow")
