@@ -133,15 +133,18 @@ def test_fuzz_context_matching(seed, b, c, r, h, w, variant, normalize):
         va[:, :, 0] = 0.0                                        # a reference that never overlaps: the `zeros` branch
     va = up(va, 3)
     tcf = T(cf, True)
+    imp = None
     if variant == "default":
-        p_in, c_mask, _ = cpn.CPNContextMatchingDefault()(tcf, T(vt), T(va), normalize=normalize)
+        p_in, c_mask, imp = cpn.CPNContextMatchingDefault()(tcf, T(vt), T(va), normalize=normalize)
     elif variant == "complete":
-        p_in, c_mask, _ = cpn.CPNContextMatchingComplete()(tcf, T(vt), T(va), normalize=normalize)
+        p_in, c_mask, imp = cpn.CPNContextMatchingComplete()(tcf, T(vt), T(va), normalize=normalize)
     else:
         p_in, c_mask = cpn_original.CM_Module()(tcf, T(vt), T(va))
-    rp, rm, _ = O.context_matching(cf, vt, va, normalize, variant)
+    rp, rm, rimp = O.context_matching(cf, vt, va, normalize, variant)
     assert_close(N(p_in), rp, what="ctx p_in")
     assert_close(N(c_mask), rm, what="ctx c_mask")
+    if imp is not None:
+        assert_close(N(imp), rimp, what="ctx ref_importance")
     cot_p = rng.standard_normal(rp.shape).astype(np.float32)
     cot_m = rng.standard_normal(rm.shape).astype(np.float32)
     (g_cf,) = torch.autograd.grad((p_in * T(cot_p)).sum() + (c_mask * T(cot_m)).sum(), [tcf])
