@@ -16,6 +16,8 @@
 // same permutation on both operands, so a k-contiguous operand is fetched from LDS with one ds_read_b128
 // per lane (rows padded to 36 floats: conflict-free) and an m-contiguous one with plain ds_read_b32.
 #include "tcl_common.h"
+#include <map>
+#include <utility>
 #include <mutex>
 #include <type_traits>
 
@@ -1538,6 +1540,128 @@ __global__ void __launch_bounds__(WM *WN * 64, (BM / WM) * (BN / WN) > 128 * 64 
   gemm_epilogue<BM, BN, WM, WN, EPI, FULL, SMEM_F>(acc, reinterpret_cast<float *>(smem), g, z, m0, n0, tn);
 }
 
+// Backward products of the bf16 variants on the same pipeline (full tiles only; other shapes keep gemm_bf16_kernel):
+//   D[m][n] = sum over segments and k of A[m][k] B[n or k][...]:  A = the forward's bf16 image of r^ / a^ (k contiguous, TileLoaderKC16,
+//   [row][k] LDS image, plain 16-byte fragment reads), B = the fp32 cotangent volume, k-contiguous (d_a: B_KC) or row-contiguous (d_r),
+//   converted to bf16 (hi, lo) while it is staged.  Two LDS stages, one barrier per k-tile, D k-tiles of both operands in flight in
+//   registers: the round-2 loop had ONE k-tile (24 KB per block) on its way from HBM, less than the loaded latency x the rate wanted.
+template <int BM, int BN, int WM, int WN, int NS, bool B_KC, int D>
+__global__ void __launch_bounds__(WM *WN * 64, 2) gemm_bf16bwd_kernel(GemmArgs g, Bf16Ops o) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_IMG = ImgSize<BM, true>::value, B_IMG = ImgSize<BN, B_KC>::value, STAGE = NS * (A_IMG + B_IMG);
+  constexpr int SMEM_F = 2 * STAGE / 2;
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem_bf16bwd[];
+  __bf16 *smem = smem_bf16bwd;
+
+  const unsigned per_batch = g.tiles_m * g.tiles_n;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned z = lin / per_batch, local = lin - z * per_batch;
+  constexpr unsigned GROUP = 8;
+  const unsigned gw = GROUP * g.tiles_n;
+  const unsigned gid = local / gw, first_m = gid * GROUP;
+  const unsigned gsz = min((unsigned)g.tiles_m - first_m, GROUP);
+  const unsigned tm = first_m + (local % gw) % gsz, tn = (local % gw) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
+
+  const int64_t a_base = (int64_t)(z / g.a_bdiv) * g.a_bs + (int64_t)m0 * g.a_ld;
+  const float *Bb = g.B + (int64_t)z * g.b_bs + (B_KC ? (int64_t)n0 * g.b_ld : n0);
+  f32x16 acc[TM][TN];
+
+  TileLoaderKC16<BM, NT> la[D][NS];
+  TileLoaderH<BN, NT, B_KC, true, NS> lb[D];
+  const int ktiles = g.K / BKH, total = ktiles * g.nseg;
+  uint32_t a_off[la[0][0].NV], b_off[lb[0].NV];
+  la[0][0].thread_offsets(a_off, g.a_ld, tid);
+  lb[0].thread_offsets(b_off, g.b_ld, tid);
+  __amdgpu_buffer_rsrc_t ra[NS], rb;
+  ra[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(o.a_hi + a_base), 0, 0x7fffffff, 0x00020000);
+  if (NS == 2) ra[NS - 1] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(o.a_lo + a_base), 0, 0x7fffffff, 0x00020000);
+  rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Bb), 0, 0x7fffffff, 0x00020000);
+  const int a_k = BKH, b_k = (int)lb[0].kstep(g.b_ld);   // elements from one k-tile to the next
+  auto fetch = [&](auto setc, int t) {   // k-tile t (counted over the segments) -> register set SET
+    constexpr int SET = decltype(setc)::value;
+    const int seg = g.nseg == 1 ? 0 : t / ktiles, kt = t - seg * ktiles;
+    const int sa = (seg * (int)g.a_ss + kt * a_k) * 2, sb = (seg * (int)g.b_ss + kt * b_k) * 4;
+#pragma unroll
+    for (int h = 0; h < NS; ++h) la[SET][h].load_buf(ra[h], a_off, sa);
+    lb[SET].load_buf(rb, b_off, sb);
+  };
+  auto stage = [&](auto setc, int st) {   // register set SET -> LDS stage st: [A hi][A lo][B hi][B lo]
+    constexpr int SET = decltype(setc)::value;
+    __bf16 *base = smem + st * STAGE;
+#pragma unroll
+    for (int h = 0; h < NS; ++h) la[SET][h].store(base + h * A_IMG, tid);
+    lb[SET].store(base + NS * A_IMG, base + NS * A_IMG + (NS - 1) * B_IMG, tid);
+  };
+  struct Frags { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto read_frags = [&](Frags &f, int st, int ks) {
+    const __bf16 *Ah = smem + st * STAGE, *Al = Ah + (NS - 1) * A_IMG, *Bh = Ah + NS * A_IMG, *Bl = Bh + (NS - 1) * B_IMG;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      f.ah[i] = read_frag_h<BM, true>(Ah, wm0 + i * 32, ks, lane);
+      if (NS == 2) f.al[i] = read_frag_h<BM, true>(Al, wm0 + i * 32, ks, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f.bh[j] = read_frag_h<BN, B_KC>(Bh, wn0 + j * 32, ks, lane);
+      if (NS == 2) f.bl[j] = read_frag_h<BN, B_KC>(Bl, wn0 + j * 32, ks, lane);
+    }
+  };
+  auto mma = [&](const Frags &f, auto firstc) {
+    constexpr bool FIRST = decltype(firstc)::value;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (NS == 2) {   // same term order as gemm_bf16_kernel: results stay bit-identical with the round-2 kernel
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[j], f.al[i], FIRST ? zero : acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[j], f.ah[i], (FIRST && NS == 1) ? zero : acc[i][j], 0, 0, 0);
+      }
+  };
+  Frags f0, f1;
+  using S0 = std::integral_constant<int, 0>;
+  fetch(S0{}, 0);
+  stage(S0{}, 0);
+  {
+    auto pre = [&](auto jc) { constexpr int J = decltype(jc)::value; if (J <= D) fetch(std::integral_constant<int, J % D>{}, min(J, total - 1)); };
+    pre(std::integral_constant<int, 1>{}); pre(std::integral_constant<int, 2>{});
+    static_assert(D <= 2, "prologue covers D <= 2");
+  }
+  __syncthreads();
+  read_frags(f0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  auto ktile = [&](auto uc, int t, auto firstc) {   // as in gemm_bf16op_kernel
+    constexpr int U = decltype(uc)::value;
+    if (U >= D) return;
+    const int st = D % 2 == 0 ? (U & 1) : ((t + U) & 1);
+    using NEXT = std::integral_constant<int, (U + 1) % D>;
+    read_frags(f1, st, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f0, std::integral_constant<bool, decltype(firstc)::value && U == 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    stage(NEXT{}, 1 - st);
+    fetch(NEXT{}, min(t + U + 1 + D, total - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_frags(f0, 1 - st, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1, std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto trip = [&](auto firstc, int t) { ktile(std::integral_constant<int, 0>{}, t, firstc); ktile(std::integral_constant<int, 1>{}, t, firstc); };
+  trip(std::true_type{}, 0);
+#pragma unroll 1
+  for (int t = D; t < total; t += D) trip(std::false_type{}, t);
+  __syncthreads();
+  gemm_epilogue<BM, BN, WM, WN, EPI_STORE, true, SMEM_F>(acc, reinterpret_cast<float *>(smem), g, z, m0, n0, tn);
+}
+
 // Measured at C2 (round 3, profiles/r3_bf16_kloop_ablations.txt): 128 x 128 tiles with two k-tiles in flight.  256 x 128 tiles
 // (4 waves of 128 x 64, or 8 of 64 x 64): store variant 0.258 / 0.287 ms against 0.224, fused argmax 0.228 / 0.241 against 0.225;
 // 256 x 256 tiles (4 waves of 128 x 128, one wave per SIMD, this same two-group pipeline): fused argmax kernel 223 us against 157;
@@ -1553,17 +1677,20 @@ constexpr int BF16_D = 2;
 template <typename K>
 static bool bf16op_lds_ready(K kernel, size_t lds) {
   if (lds <= 64 * 1024) return true;
+  // keyed by (kernel, device): every instantiation has the same function-pointer type, so a per-type cache would ask for one only
   static std::mutex mu;
-  static signed char ok[64];   // 0 = not asked yet, 1 = granted, -1 = refused
+  static std::map<std::pair<const void *, int>, bool> asked;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
   std::lock_guard<std::mutex> lock(mu);
-  if (ok[dev] == 0) {
+  const auto key = std::make_pair((const void *)kernel, dev);
+  auto it = asked.find(key);
+  if (it == asked.end()) {
     const bool granted = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     if (!granted) (void)hipGetLastError();
-    ok[dev] = granted ? 1 : -1;
+    it = asked.emplace(key, granted).first;
   }
-  return ok[dev] > 0;
+  return it->second;
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -1626,6 +1753,26 @@ static int launch_gemm_bf16(GemmArgs g, const Bf16Ops &o, int nsplit, hipStream_
   if (vec && a16_vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BKH == 0 && (int64_t)BM * g.d_ld * 4 < (1LL << 31) &&
       (int64_t)g.nseg * g.a_ss * 4 + (int64_t)(A_KC ? BM : g.K) * g.a_ld * 4 < (1LL << 31) &&
       (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? BN : g.K) * g.b_ld * 4 < (1LL << 31)) {   // full tiles (31-bit buffer offsets): cursor loads, no predication
+    // the pipelined kernel on 256 x 128 eight-wave tiles when the shape divides (it has no ragged path), else the round-2 loop
+    if (A_KC && g.M % 256 == 0 && g.N % 128 == 0 && (int64_t)g.nseg * g.b_ss * 4 + (int64_t)(B_KC ? 128 : g.K) * g.b_ld * 4 < (1LL << 31)) {
+      GemmArgs p = g;
+      p.tiles_m = g.M / 256; p.tiles_n = g.N / 128;
+      const int64_t pblocks = (int64_t)p.tiles_m * p.tiles_n * p.nbatch;
+      const int total = g.K / BKH * g.nseg;
+#define TCL_BWD_PIPE(NSV, DV)                                                                                       \
+  do {                                                                                                               \
+    auto kern = gemm_bf16bwd_kernel<256, 128, 4, 2, NSV, B_KC, DV>;                                                  \
+    constexpr size_t lds = (size_t)2 * NSV * (ImgSize<256, true>::value + ImgSize<128, B_KC>::value) * 2;            \
+    if (pblocks < (1LL << 31) && bf16op_lds_ready(kern, lds)) {                                                      \
+      hipLaunchKernelGGL(kern, dim3((unsigned)pblocks), dim3(512), lds, s, p, o);                                    \
+      return check_launch(what);                                                                                     \
+    }                                                                                                                \
+  } while (0)
+      // bf16x3 only: with one MFMA per product (bf16) the round-2 loop at four waves per SIMD is faster (0.842 against 0.864-0.885 ms
+      // for the leg), with three the pipeline wins (1.47-1.53 against 1.57-1.63 ms)
+      if (nsplit == 2 && total % 2 == 0) TCL_BWD_PIPE(2, 2);   // (both products have K = N = P: a multiple of 128 here, so always)
+#undef TCL_BWD_PIPE
+    }
     if (nsplit == 2) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 2, true, true>), grd, blk, 0, s, g, o);
     else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, A_KC, B_KC, true, 1, true, true>), grd, blk, 0, s, g, o);
     return check_launch(what);

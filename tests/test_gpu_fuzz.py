@@ -238,8 +238,11 @@ def test_fuzz_inference_unit_equals_unfused(seed, b, f, h, w):
 def _mid_cases():
     rng = np.random.default_rng(13)
     sizes = [(24, 24), (32, 32), (40, 40), (48, 48), (56, 56), (64, 64), (30, 53), (20, 77)]
-    return [(i, int(rng.integers(1, 3)), int(rng.choice([64, 96, 200, 256, 512])), int(rng.integers(1, 3)),
-             *sizes[int(rng.integers(0, len(sizes)))], int(rng.integers(0, 3))) for i in range(18)]
+    cases = [(i, int(rng.integers(1, 3)), int(rng.choice([64, 96, 200, 256, 512])), int(rng.integers(1, 3)),
+              *sizes[int(rng.integers(0, len(sizes)))], int(rng.integers(0, 3))) for i in range(18)]
+    # shapes the pipelined bf16x3 backward takes (C % 256 == 0, P % 128 == 0), several reference frames = k segments of d_a
+    cases += [(100, 1, 256, 2, 32, 32, 1), (101, 2, 512, 3, 16, 16, 1), (102, 1, 256, 1, 16, 24, 1), (103, 1, 256, 2, 16, 24, 2), (104, 1, 256, 3, 32, 32, 0)]
+    return cases
 
 
 @pytest.mark.parametrize("seed,b,c,f,h,w,prec", _mid_cases())
