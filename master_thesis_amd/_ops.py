@@ -69,7 +69,7 @@ def _workspace(nbytes, dev, cache=False):
     stream is ordered, so two calls never use it at once, and the one-pair inference loops of the sequence schedulers
     (thousands of identical calls) stop going through the allocator."""
     n = max(int(nbytes), 256)
-    if not cache:
+    if not cache or torch.cuda.is_current_stream_capturing():   # a buffer made during graph capture belongs to that graph's pool
         return torch.empty(n, dtype=torch.uint8, device=dev)
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, n)
     buf = _WS_CACHE.get(key)

@@ -838,3 +838,31 @@ def test_warp_hole_mask_flip_equals_one_minus_m():
         xb, vb = _ops.WarpFn.apply(T(x), 1 - T(m), grid, th, ac, mode)
         assert_exact(N(xa), N(xb), what="x")
         assert_exact(N(va), N(vb), what="v")
+
+
+def test_argmax_flow_under_graph_capture_and_after():
+    """The fused argmax (cached workspace outside capture, a private one inside) captured in a HIP graph, replayed on new inputs, and
+    called eagerly again afterwards: all three agree with the eager result."""
+    from master_thesis_amd import _ops
+    g = torch.Generator().manual_seed(5)
+    xt = torch.randn(1, 64, 16, 16, generator=g).to(DEV)
+    xr = torch.randn(1, 64, 2, 16, 16, generator=g).to(DEV)
+    eager = _ops.corr4d_argmax_flow(xt, None, xr, None).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _ops.corr4d_argmax_flow(xt, None, xr, None)          # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = _ops.corr4d_argmax_flow(xt, None, xr, None)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert_exact(N(captured), N(eager), what="graph replay")
+    xt2 = torch.randn(1, 64, 16, 16, generator=g).to(DEV)
+    eager2 = _ops.corr4d_argmax_flow(xt2, None, xr, None).clone()
+    xt.copy_(xt2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert_exact(N(captured), N(eager2), what="graph replay on new inputs")
+    assert_exact(N(_ops.corr4d_argmax_flow(xt2, None, xr, None)), N(eager2), what="eager after capture")
